@@ -1,0 +1,145 @@
+/*
+ * lsq_hip.h -- C ABI of the MI355X (gfx950) least-squares binary quantized forward path.
+ *
+ * The reference (apple/ml-quant) is pure Python on stock torch ops and has no FFI of its
+ * own; each entry point below replaces the Python functions cited next to it (paths are
+ * relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add to `QuantConv2d.forward` (quant/binary/binary_conv.py:161-173).
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (torch allocator); the library
+ *    allocates nothing, keeps no global state and is re-entrant per stream.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - Every function returns 0 on success, a negative LSQ_E_* code for an argument error,
+ *    or a positive hipError_t if a launch failed.
+ *  - Activations are NCHW fp32, one "row" = one sample (quantization.py:77); weights are
+ *    [O][C/groups][KH][KW] fp32, one row = one output channel.
+ *
+ * Packed sign planes ("bit tensors")
+ *  - Activation plane p of a batch: uint64 words [p][N][Gt][Hp][Wp] with
+ *        cg = C / groups,  Gg = ceil(cg / 64),  Gt = groups * Gg,
+ *        Hp = H + 2*pad_h, Wp = W + 2*pad_w.
+ *    Word (n, grp*Gg + j, h + pad_h, w + pad_w) holds, in bit b, the sign of channel
+ *    grp*cg + 64*j + b at pixel (h, w): 1 <=> value >= 0 (so sign(+-0) = +1,
+ *    quant/binary/ste.py:16-18), 0 for channels beyond cg.  The halo words are never
+ *    written: the caller zero-fills the buffer once (zero words = all -1, corrected
+ *    analytically in the conv epilogue so padded taps contribute exactly 0).
+ *  - Weight plane q: uint64 words [q][KH*KW][Gg][O]; bit b of word (tap, j, o) is the sign of
+ *    w[o][64*j + b][tap]; int32 tap sums wsum[q][O][KH*KW] = sum_c sign(w[o][c][tap]).
+ */
+#ifndef LSQ_HIP_H_
+#define LSQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSQ_ABI_VERSION 1
+
+/* quantization schemes (quant/binary/binary_conv.py:99-101) */
+enum {
+  LSQ_SCHEME_LS1 = 1, /* quantizer_ls_1       quantization.py:35-56  */
+  LSQ_SCHEME_LS2 = 2, /* quantizer_ls_2       quantization.py:59-92  */
+  LSQ_SCHEME_LST = 3, /* quantizer_ls_ternary quantization.py:95-115 */
+  LSQ_SCHEME_GF = 4   /* quantizer_gf (k planes) quantization.py:118-148 */
+};
+
+enum {
+  LSQ_OK = 0,
+  LSQ_E_NULL = -1,      /* required pointer is NULL */
+  LSQ_E_SHAPE = -2,     /* non-positive / inconsistent dimension */
+  LSQ_E_SCHEME = -3,    /* unknown scheme or plane count */
+  LSQ_E_TOO_LONG = -4,  /* a sub-sampled row has >= 2^22 elements */
+  LSQ_E_WORKSPACE = -5, /* workspace too small */
+  LSQ_E_UNSUPPORTED = -6
+};
+
+#define LSQ_MAX_PLANES 8
+
+int lsq_abi_version(void);
+const char* lsq_error_string(int code);
+
+/* Geometry of one QuantConv2d call (nn.Conv2d arguments, binary_conv.py:165-173). */
+typedef struct lsq_conv_geom {
+  int32_t N, C, H, W;      /* input  */
+  int32_t O, KH, KW;       /* weight [O][C/groups][KH][KW] */
+  int32_t stride_h, stride_w;
+  int32_t pad_h, pad_w;
+  int32_t dil_h, dil_w;
+  int32_t groups;
+} lsq_conv_geom;
+
+/* number of uint64 words of ONE activation plane for `g` (N * Gt * Hp * Wp) */
+int64_t lsq_act_plane_words(const lsq_conv_geom* g);
+/* number of uint64 words of ONE weight plane (KH*KW * Gg * O) */
+int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
+
+/*
+ * Activation quantization: clamp -> per-sample scale solve -> packed sign planes.
+ * Replaces ActivationQuantizer*._batch_quantization / _moving_average_quantization
+ * (quant/binary/activation_quantization.py:68-102) together with clamp_symmetric
+ * (quantization.py:22-24), opt_v1 / compute_mask / cost_function (optimal.py:16-155).
+ *
+ *   x            [N][C][H][W] fp32
+ *   scheme,k     LS1: k=1; LS2, LST: k=2; GF: k = number of bits (1..LSQ_MAX_PLANES)
+ *   skip         sub-sampling stride of the v1 search (quantization.py:63; 3 in the reference)
+ *   clamp_alpha  symmetric clamp bound, or a negative value for clamp_identity
+ *   forced       NULL, or [k][N] scales to use instead of solving (eval with moving average,
+ *                activation_quantization.py:90-98)
+ *   planes       out, [k] activation planes laid out as described above (halo pre-zeroed)
+ *   scales       out, [k][N] fp32: v1..vk per sample (LST: row 1 repeats v1)
+ */
+int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
+                  float clamp_alpha, const float* forced, uint64_t* planes, float* scales,
+                  void* stream);
+
+/*
+ * Stand-alone optimal-v1 solve on a dense [R][M] fp32 matrix (rows need not be activations):
+ * opt_v1(matrix, ternary, skip) of quant/binary/optimal.py:121-155 followed, for the
+ * non-ternary case, by v2 = mean|x - v1 sign(x)| over the full row (quantization.py:84-85).
+ *   v12 [2][R] out: row 0 = v1, row 1 = v2 (ternary: v2 = v1);  status [R] out (may be NULL):
+ *   number of distinct candidate values found (0 => v1 = 0, the reference's zero padding wins).
+ */
+int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,
+                   float clamp_alpha, float* v12, int32_t* status, void* stream);
+
+/*
+ * Weight sign packing with cached per-output-channel scales (eval mode):
+ * replaces WeightQuantizer*.forward in eval (quant/binary/weight_quantization.py:32-34,
+ * :57-58, :80-81, :106-108) -- plane q = sign(w - sum_{r<q} u_r * plane_r).
+ *   w       [O][C/groups][KH][KW] fp32
+ *   scales  [k][O] fp32 (the module's v1..vk buffers)
+ *   wbits   out, [k] weight planes;  wsum out, [k][O][KH*KW] int32
+ */
+int lsq_pack_weight(const float* w, const lsq_conv_geom* g, int k, const float* scales,
+                    uint64_t* wbits, int32_t* wsum, void* stream);
+
+/*
+ * Binary x binary convolution by XNOR + popcount:
+ *   y[n][o] = bias[o] + sum_p sum_q xs[p][n] * ws[q][o] * (plane_p (*) wplane_q)[n][o]
+ * which equals F.conv2d(x_q, w_q, bias, ...) of binary_conv.py:165-173 for
+ * x_q = sum_p xs_p b_p, w_q = sum_q ws_q s_q (exact integer inner products).
+ *   kx, kw_planes  number of activation / weight planes
+ *   y              out, [N][O][Ho][Wo] fp32
+ */
+int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
+                    const uint64_t* wbits, const int32_t* wsum, int kw_planes,
+                    const float* wscales, const float* bias, const lsq_conv_geom* g,
+                    float* y, void* stream);
+
+/*
+ * Full-precision activation x sign-weight convolution on bf16 MFMA (x split hi+lo):
+ *   y[n][o] = bias[o] + sum_q ws[q][o] * conv(clamp(x), wplane_q)[n][o]
+ * Replaces F.conv2d(x, w_q, ...) of binary_conv.py:165-173 when x_quant == 'fp'.
+ */
+int lsq_signw_conv2d(const float* x, float clamp_alpha, const uint64_t* wbits, int kw_planes,
+                     const float* wscales, const float* bias, const lsq_conv_geom* g,
+                     float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQ_HIP_H_ */

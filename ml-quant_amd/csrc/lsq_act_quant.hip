@@ -1,0 +1,858 @@
+// Activation quantization for gfx950: clamp -> per-row optimal-scale solve -> packed sign planes.
+//
+// One 1024-thread workgroup owns one row (one sample, quantization.py:77) from the first
+// byte read to the last word written, so every cross-pass hand-off stays inside a CU (LDS +
+// registers); rows are independent, so a batch of N rows is a grid of N workgroups.
+//
+// The optimal-v1 solve (quant/binary/optimal.py:41-155) never sorts.  It is a three-level
+// radix select over the IEEE bit pattern of |x| (12 + 10 + 9 bits).  Each histogram bin
+// accumulates, with ONE 64-bit LDS atomic per element, its count and the exact integer sum
+// of the low key bits; within a bin the exponent is fixed, so value = 2^e * mantissa is
+// linear in those bits and the bin's sum, hence rank and prefix sum at every bin boundary,
+// is exact.  m1(i), m2(i) of optimal.py:66-74 are monotone in the sorted position i, so only
+// bins whose value range can intersect them are refined (typically 2-4 of 4096); their keys
+// are gathered once into LDS and levels 2 and 3 run from LDS.  Level 3 bins are single
+// keys: candidates are tested exactly (fp64) and their least-squares cost is evaluated in
+// closed form from the prefix sums, replacing the reference's [N,K,M] broadcast
+// (optimal.py:31-38).  oracle/radix_select_model.py is the host model of this file.
+//
+// Memory traffic per row of M floats: pass 0 reads M (plane 0 + level-1 histogram), the
+// gather pass touches the sub-sample (every line of the row at skip=3), pass 1 reads M
+// (plane 1 + v2).  Writes are M/32 bytes per plane.  Algorithmic minimum is one read of M.
+
+#include <type_traits>
+
+#include "lsq_common.h"
+
+namespace lsq {
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / kWave;
+constexpr int L1_SHIFT = 19, L1_BINS = 4096;   // key bits [30:19]
+constexpr int L2_SHIFT = 9, L2_BINS = 1024;    // key bits [18:9]
+constexpr int L3_BINS = 512;                   // key bits [8:0]
+constexpr int kSlots1 = 64;                    // level-1 bins refined per round
+constexpr int kSeg3 = 8;                       // level-2 bins refined per level-3 pass
+constexpr int kListCap = 14336;                // gathered keys held in LDS
+constexpr unsigned kNoKey = 0xFFFFFFFFu;
+constexpr unsigned long long kOne = 1ull << 42;          // count field of a histogram word
+constexpr unsigned long long kLowMask = kOne - 1;
+constexpr double kSlack = 1e-9;
+
+struct Best {
+  double cost;
+  unsigned order;
+  float value;
+};
+
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+  return a.cost < b.cost || (a.cost == b.cost && a.order < b.order);
+}
+
+struct Slot1 {
+  unsigned bin, next_bin, cnt, r0;
+  double p0, sum;
+};
+
+struct Seg3 {
+  unsigned pref, next_pref, cnt, r0;
+  double p0;
+};
+
+struct SolverLds {
+  unsigned long long hist1[L1_BINS];
+  unsigned long long hist2[L2_BINS];
+  unsigned hist3[kSeg3][L3_BINS];
+  unsigned list[kListCap];
+  unsigned short nzlist[L1_BINS];
+  unsigned char role[L1_BINS];
+  Slot1 slot[kSlots1];
+  unsigned succ1[kSlots1];
+  Seg3 seg[kSeg3];
+  unsigned succ3[kSeg3];
+  // block-scan scratch
+  unsigned wa[kWaves], wb[kWaves], wc[kWaves];
+  double ws[kWaves];
+  Best wbest[kWaves];
+  // scalars
+  unsigned list_n, n_flag, n_cand, round_cnt;
+  unsigned minkey;
+  double total;
+  float sv[LSQ_MAX_PLANES];
+};
+
+struct SmallLds {
+  double ws[kWaves];
+  float sv[LSQ_MAX_PLANES];
+};
+
+struct Args {
+  const float* x;
+  long long row_elems;      // M = C*H*W (or M of the flat matrix)
+  int C, H, W, cg, Gg, Gt, Hp, Wp, pad_h, pad_w;
+  int scheme, k, skip;
+  float alpha;
+  const float* forced;      // [k][N] or null
+  unsigned long long* planes;
+  long long plane_words;    // words of one plane (all rows)
+  long long row_words;      // words of one row of one plane
+  float* scales;            // [k][N]
+  int* status;              // flat mode: number of candidates per row
+  int N;
+  int flat;                 // 1: dense [R][M] rows, no planes
+  int ternary;
+};
+
+// exact sum of a histogram bin whose keys share `hi_key` above the low bits
+__device__ __forceinline__ double bin_sum_exact(unsigned hi_key, unsigned cnt, unsigned long long lowsum) {
+  const int e = (int)(hi_key >> 23);
+  long long mant = (long long)(hi_key & 0x7FFFFFu);
+  int sc = -149;
+  if (e > 0) {
+    mant += 1ll << 23;
+    sc = e - 150;
+  }
+  const long long integer = (long long)cnt * mant + (long long)lowsum;
+  return ldexp((double)integer, sc);
+}
+
+struct MPair {
+  double m2, m1;
+};
+__device__ __forceinline__ MPair m_pair(double lo_cnt, double lo_sum, double n, double total) {
+  const double hi_mean = (total - lo_sum) / (n - lo_cnt);
+  MPair r;
+  r.m2 = 0.5 * hi_mean;                          // optimal.py:74
+  r.m1 = 0.5 * (lo_sum / lo_cnt + hi_mean);      // optimal.py:73
+  return r;
+}
+
+// Can a position inside [r0, r0+cnt) be a candidate (optimal.py:78-80)?  Conservative.
+__device__ bool may_hold_candidate(unsigned r0, unsigned cnt, double p0, double s, double vlo, double vhi,
+                                   double next_hi, unsigned n, double total, bool ternary) {
+  const long long r1 = (long long)r0 + cnt;
+  const long long ilo = r0 > 1u ? (long long)r0 : 1ll;
+  const long long ihi = (r1 - 1) < ((long long)n - 2) ? (r1 - 1) : ((long long)n - 2);
+  if (ilo > ihi) return false;
+  double m2_lo, m1_lo, m2_hi, m1_hi, succ_hi;
+  if (r0 >= 1u) {
+    const MPair m = m_pair((double)r0, p0, (double)n, total);
+    m2_lo = m.m2;
+    m1_lo = m.m1;
+  } else {
+    m2_lo = m1_lo = 0.5 * (total - vhi) / ((double)n - 1.0);
+  }
+  if (r1 <= (long long)n - 1) {
+    const MPair m = m_pair((double)r1, p0 + s, (double)n, total);
+    m2_hi = m.m2;
+    m1_hi = m.m1;
+    succ_hi = next_hi;
+  } else {
+    m2_hi = 0.5 * vhi;
+    m1_hi = vhi;
+    succ_hi = vhi;
+  }
+  const double up = 1.0 + kSlack, dn = 1.0 - kSlack;
+  bool hit = (m2_hi * up >= vlo) && (m2_lo * dn <= succ_hi);
+  if (!ternary) hit = hit || ((m1_hi * up >= vlo) && (m1_lo * dn <= succ_hi));
+  return hit;
+}
+
+__device__ __forceinline__ bool position_is_candidate(double v, double nxt, double lo_cnt, double lo_sum,
+                                                      double n, double total, bool ternary) {
+  const MPair m = m_pair(lo_cnt, lo_sum, n, total);
+  bool hit = (v <= m.m2) && (m.m2 <= nxt);
+  if (!ternary) hit = hit || ((v <= m.m1) && (m.m1 <= nxt));
+  return hit;
+}
+
+// A run of `c` equal keys of value v at sorted positions [r0, r0+c): is any position a candidate?
+__device__ bool run_has_candidate(double v, unsigned c, unsigned r0, double p0, double succ_v, unsigned n,
+                                  double total, bool ternary) {
+  const double dn = (double)n;
+  // last element of the run: successor is the next distinct value
+  {
+    const long long i = (long long)r0 + c - 1;
+    if (i >= 1 && i <= (long long)n - 2 &&
+        position_is_candidate(v, succ_v, (double)(i + 1), p0 + (double)c * v, dn, total, ternary))
+      return true;
+  }
+  if (c < 2u) return false;
+  // interior positions: a[i] == a[i+1] == v, so m must equal v exactly
+  long long tlo = 0, thi = (long long)c - 2;
+  if ((long long)r0 + tlo < 1) tlo = 1 - (long long)r0;
+  if ((long long)r0 + thi > (long long)n - 2) thi = (long long)n - 2 - (long long)r0;
+  if (tlo > thi) return false;
+  if (thi - tlo < 64) {
+    for (long long t = tlo; t <= thi; ++t)
+      if (position_is_candidate(v, v, (double)(r0 + t + 1), p0 + (double)(t + 1) * v, dn, total, ternary))
+        return true;
+    return false;
+  }
+  // long runs: m2, m1 are monotone in t -> first t with m >= v must hit v exactly
+  for (int which = 0; which < (ternary ? 1 : 2); ++which) {
+    long long lo = tlo, hi = thi;
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      const MPair m = m_pair((double)(r0 + mid + 1), p0 + (double)(mid + 1) * v, dn, total);
+      if ((which ? m.m1 : m.m2) >= v) hi = mid; else lo = mid + 1;
+    }
+    const MPair m = m_pair((double)(r0 + lo + 1), p0 + (double)(lo + 1) * v, dn, total);
+    if ((which ? m.m1 : m.m2) == v) return true;
+  }
+  return false;
+}
+
+// closed-form cost^2 (minus the constant sum a^2) of candidate v (optimal.py:31-38)
+__device__ __forceinline__ double cost_of(double v, unsigned below_cnt, double below_sum, unsigned eq_cnt,
+                                          unsigned n, double total, bool ternary) {
+  const double dn = (double)n;
+  const double above_cnt = dn - (double)below_cnt - (double)eq_cnt;
+  const double above_sum = total - below_sum - (double)eq_cnt * v;
+  const double dev = (v * (double)below_cnt - below_sum) + (above_sum - v * above_cnt);
+  const double quad = -2.0 * v * total + dn * v * v;
+  if (ternary) return quad - 2.0 * v * dev + dn * v * v;
+  return quad - dev * dev / dn;
+}
+
+// exclusive block scan of (a, b, s); returns block totals. All 1024 threads must call.
+template <class L>
+__device__ void block_excl_scan(unsigned& a, unsigned& b, double& s, unsigned& ta, unsigned& tb, double& ts,
+                                L* lds) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+  const double is = wave_incl_scan(s);
+  __syncthreads();
+  if (lane == 63) {
+    lds->wa[wid] = ia;
+    lds->wb[wid] = ib;
+    lds->ws[wid] = is;
+  }
+  __syncthreads();
+  unsigned oa = 0, ob = 0;
+  double os = 0.0;
+  ta = tb = 0;
+  ts = 0.0;
+  for (int w = 0; w < kWaves; ++w) {
+    if (w == wid) {
+      oa = ta;
+      ob = tb;
+      os = ts;
+    }
+    ta += lds->wa[w];
+    tb += lds->wb[w];
+    ts += lds->ws[w];
+  }
+  a = oa + ia - a;
+  b = ob + ib - b;
+  s = os + (is - s);
+}
+
+template <class L>
+__device__ double block_sum(double v, L* lds) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds->ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < kWaves; ++w) t += lds->ws[w];
+  return t;
+}
+
+__device__ __forceinline__ unsigned mod_small(unsigned r, unsigned m) {
+  // r < m + 4
+  if (r >= m) r -= m;
+  if (r >= m) r -= m;
+  if (r >= m) r -= m;
+  if (r >= m) r -= m;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One streaming pass over the row: plane q bits, sum |residual_q|, optional level-1 histogram.
+// result chain / residual chain exactly as quantization.py:89-92, :112-115, :137-146.
+struct Chain {
+  int q;
+  float v[LSQ_MAX_PLANES];   // wave-uniform (SGPRs)
+};
+
+// QM = 0: plane 0 (no scale yet); QM = 1: plane 1 (one scale); QM = 2: any depth
+template <int QM>
+__device__ __forceinline__ void chain_eval(const Chain& ch, float xv, bool& bit, float& absres) {
+  if constexpr (QM == 0) {
+    bit = xv >= 0.f;
+    absres = fabsf(xv);
+  } else if constexpr (QM == 1) {
+    const float v0 = ch.v[0];
+    const float r = xv - ((xv >= 0.f) ? v0 : -v0);      // x - v1*b1: one rounding, as the reference
+    bit = r >= 0.f;
+    absres = fabsf(r);
+  } else {
+    float result = 0.f, res = xv;
+#pragma unroll
+    for (int i = 0; i < LSQ_MAX_PLANES - 1; ++i) {
+      if (i < ch.q) {
+        const float vi = ch.v[i];
+        result = result + ((xv - result >= 0.f) ? vi : -vi);
+        res = res - ((res >= 0.f) ? vi : -vi);
+      }
+    }
+    bit = (xv - result) >= 0.f;
+    absres = fabsf(res);
+  }
+}
+
+template <int VEC, bool HIST, int QM, class L>
+__device__ void pack_pass(const Args& a, const float* __restrict__ xrow, unsigned long long* __restrict__ prow,
+                          const Chain& ch, double& sum_out, unsigned& minkey_out, L* lds) {
+  const int HW = a.H * a.W;
+  const int PV = (HW + VEC - 1) / VEC;
+  const int items = a.Gt * PV;
+  const unsigned skip = (unsigned)a.skip;
+  const unsigned step = (unsigned)(HW % a.skip);
+  double acc = 0.0;
+  unsigned mk = kNoKey;
+  for (int item = threadIdx.x; item < items; item += kThreads) {
+    const int j = item / PV;
+    const int p = (item - j * PV) * VEC;
+    const int grp = j / a.Gg;
+    const int jj = j - grp * a.Gg;
+    const int c0 = grp * a.cg + jj * 64;
+    const int nch = min(64, a.cg - jj * 64);
+    const float* src = xrow + (long long)c0 * HW + p;
+    unsigned long long word[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) word[v] = 0ull;
+    unsigned rem = HIST ? (unsigned)(((long long)c0 * HW + p) % (long long)skip) : 0u;
+#pragma unroll 8
+    for (int cc = 0; cc < nch; ++cc) {
+      float vals[VEC];
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (long long)cc * HW);
+        vals[0] = t.x; vals[1 % VEC] = t.y; vals[2 % VEC] = t.z; vals[3 % VEC] = t.w;
+      } else if (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src + (long long)cc * HW);
+        vals[0] = t.x; vals[1 % VEC] = t.y;
+      } else {
+        vals[0] = src[(long long)cc * HW];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float xv = clamp_sym(vals[v], a.alpha);
+        bool bit;
+        float ar;
+        chain_eval<QM>(ch, xv, bit, ar);
+        word[v] |= (unsigned long long)bit << cc;
+        acc += (double)ar;
+        if constexpr (HIST) {
+          if (mod_small(rem + v, skip) == 0u) {
+            const unsigned key = abs_key(xv);
+            atomicAdd(&lds->hist1[key >> L1_SHIFT], kOne | (unsigned long long)(key & ((1u << L1_SHIFT) - 1u)));
+            mk = min(mk, key);
+          }
+        }
+      }
+      if constexpr (HIST) {
+        rem += step;
+        if (rem >= skip) rem -= skip;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int pix = p + v;
+      const int h = pix / a.W;
+      const int w = pix - h * a.W;
+      prow[((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w] = word[v];
+    }
+  }
+  sum_out = acc;
+  minkey_out = mk;
+}
+
+// flat rows (no planes): sum |residual| and optional histogram, coalesced
+template <bool HIST, int QM, class L>
+__device__ void flat_pass(const Args& a, const float* __restrict__ xrow, const Chain& ch, double& sum_out,
+                          unsigned& minkey_out, L* lds) {
+  const long long M = a.row_elems;
+  const unsigned skip = (unsigned)a.skip;
+  double acc = 0.0;
+  unsigned mk = kNoKey;
+  for (long long i = threadIdx.x; i < M; i += kThreads) {
+    const float xv = clamp_sym(xrow[i], a.alpha);
+    bool bit;
+    float ar;
+    chain_eval<QM>(ch, xv, bit, ar);
+    acc += (double)ar;
+    if constexpr (HIST) {
+      if ((i % skip) == 0) {
+        const unsigned key = abs_key(xv);
+        atomicAdd(&lds->hist1[key >> L1_SHIFT], kOne | (unsigned long long)(key & ((1u << L1_SHIFT) - 1u)));
+        mk = min(mk, key);
+      }
+    }
+  }
+  sum_out = acc;
+  minkey_out = mk;
+}
+
+// sub-sampled keys of the row (optimal.py:134), straight from memory (L2 / Infinity Cache)
+template <class F>
+__device__ __forceinline__ void for_each_row_key(const Args& a, const float* __restrict__ xrow, unsigned n, F f) {
+  for (unsigned j = threadIdx.x; j < n; j += kThreads)
+    f(abs_key(clamp_sym(xrow[(long long)j * a.skip], a.alpha)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The solve.  On entry hist1 holds the level-1 histogram of the n sub-sampled keys.
+__device__ float solve_v1(const Args& a, const float* __restrict__ xrow, unsigned n, unsigned minkey,
+                          SolverLds* lds, unsigned* n_candidates) {
+  const bool ternary = a.ternary != 0;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  Best best;
+  best.cost = INFINITY;
+  best.order = kNoKey;
+  best.value = 0.f;
+  if (tid == 0) {
+    lds->n_cand = 0;
+  }
+
+  // ---- level 1: each thread owns 4 consecutive bins
+  unsigned cnt[4], r0[4], nxt[4];
+  double sum[4], p0[4];
+  bool flag[4];
+  unsigned my_nz = 0, my_cnt = 0;
+  double my_sum = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned b = 4u * tid + u;
+    const unsigned long long h = lds->hist1[b];
+    cnt[u] = (unsigned)(h >> 42);
+    sum[u] = cnt[u] ? bin_sum_exact(b << L1_SHIFT, cnt[u], h & kLowMask) : 0.0;
+    my_nz += cnt[u] ? 1u : 0u;
+    my_cnt += cnt[u];
+    my_sum += sum[u];
+  }
+  unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
+  double esum = my_sum, total;
+  block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
+  {
+    unsigned z = enz, c = ecnt;
+    double s = esum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r0[u] = c;
+      p0[u] = s;
+      if (cnt[u]) lds->nzlist[z++] = (unsigned short)(4u * tid + u);
+      c += cnt[u];
+      s += sum[u];
+    }
+  }
+  if (tid == 0) lds->total = total;
+  __syncthreads();
+  unsigned my_flags = 0;
+  {
+    unsigned z = enz;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      flag[u] = false;
+      nxt[u] = kNoKey;
+      if (cnt[u]) {
+        const unsigned b = 4u * tid + u;
+        const double vlo = (double)key_value(b << L1_SHIFT);
+        const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        double next_hi = vhi;
+        if (z + 1 < tnz) {
+          nxt[u] = lds->nzlist[z + 1];
+          next_hi = (double)key_value((nxt[u] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        }
+        flag[u] = n >= 3u && may_hold_candidate(r0[u], cnt[u], p0[u], sum[u], vlo, vhi, next_hi, n, total, ternary);
+        my_flags += flag[u] ? 1u : 0u;
+        ++z;
+      }
+    }
+  }
+  unsigned eflag = my_flags, dummy = 0, tflag, tdummy;
+  double dzero = 0.0, tdz;
+  block_excl_scan(eflag, dummy, dzero, tflag, tdummy, tdz, lds);
+
+  // ---- rounds over flagged level-1 bins
+  for (unsigned round0 = 0; round0 < tflag; round0 += kSlots1) {
+    const unsigned nslot = min((unsigned)kSlots1, tflag - round0);
+    __syncthreads();
+    for (int i = tid; i < L1_BINS; i += kThreads) lds->role[i] = 0;
+    if (tid == 0) {
+      lds->list_n = 0;
+      lds->round_cnt = 0;
+    }
+    if (tid < kSlots1) lds->succ1[tid] = kNoKey;
+    __syncthreads();
+    {
+      unsigned ord = eflag;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (flag[u]) {
+          if (ord >= round0 && ord < round0 + nslot) {
+            Slot1 s;
+            s.bin = 4u * tid + u;
+            s.next_bin = nxt[u];
+            s.cnt = cnt[u];
+            s.r0 = r0[u];
+            s.p0 = p0[u];
+            s.sum = sum[u];
+            lds->slot[ord - round0] = s;
+            atomicAdd(&lds->round_cnt, cnt[u]);
+          }
+          ++ord;
+        }
+      }
+    }
+    __syncthreads();
+    const bool use_list = lds->round_cnt <= (unsigned)kListCap;
+    if (use_list) {
+      // role: bit 7 = gather this bin; low 7 bits = 1 + slot whose successor lives in this bin
+      if (tid < (int)nslot) {
+        const Slot1 s = lds->slot[tid];
+        atomicOr((unsigned*)&lds->role[s.bin & ~3u], 0x80u << (8 * (s.bin & 3u)));
+        if (s.next_bin != kNoKey)
+          atomicOr((unsigned*)&lds->role[s.next_bin & ~3u], (unsigned)(tid + 1) << (8 * (s.next_bin & 3u)));
+      }
+      __syncthreads();
+      for_each_row_key(a, xrow, n, [&](unsigned key) {
+        const unsigned r = lds->role[key >> L1_SHIFT];
+        if (r & 0x80u) lds->list[atomicAdd(&lds->list_n, 1u)] = key;
+        const unsigned sd = r & 0x7Fu;
+        if (sd && key < lds->succ1[sd - 1]) atomicMin(&lds->succ1[sd - 1], key);
+      });
+      __syncthreads();
+    }
+    const unsigned list_n = lds->list_n;
+
+    for (unsigned si = 0; si < nslot; ++si) {
+      const Slot1 s1 = lds->slot[si];
+      // ---- level 2 histogram of bin s1.bin
+      __syncthreads();
+      for (int i = tid; i < L2_BINS; i += kThreads) lds->hist2[i] = 0ull;
+      __syncthreads();
+      auto l2 = [&](unsigned key) {
+        const unsigned b = key >> L1_SHIFT;
+        if (b == s1.bin)
+          atomicAdd(&lds->hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
+                    kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
+        else if (!use_list && b == s1.next_bin && key < lds->succ1[si])
+          atomicMin(&lds->succ1[si], key);
+      };
+      if (use_list) {
+        for (unsigned i = tid; i < list_n; i += kThreads) l2(lds->list[i]);
+      } else {
+        for_each_row_key(a, xrow, n, l2);
+      }
+      __syncthreads();
+      const unsigned succ_b = lds->succ1[si];
+      // thread t owns sub-bin t
+      const unsigned long long h2 = lds->hist2[tid];
+      const unsigned c2 = (unsigned)(h2 >> 42);
+      const unsigned hi_key2 = (s1.bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
+      const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
+      unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
+      double es2 = s2, ts2;
+      block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
+      if (c2) lds->nzlist[enz2] = (unsigned short)tid;   // level-1 use of nzlist is over
+      __syncthreads();
+      const unsigned r02 = s1.r0 + ec2;
+      const double p02 = s1.p0 + es2;
+      unsigned next_sub = kNoKey;
+      bool f2 = false;
+      if (c2) {
+        const double vlo = (double)key_value(hi_key2);
+        const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
+        double next_hi = vhi;
+        if (enz2 + 1 < tnz2) {
+          next_sub = lds->nzlist[enz2 + 1];
+          next_hi = (double)key_value((s1.bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
+        } else if (succ_b != kNoKey) {
+          next_hi = (double)key_value(succ_b);
+        }
+        f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, lds->total, ternary);
+      }
+      unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
+      double dz2 = 0.0, tdz2;
+      block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
+
+      // ---- level 3 in batches of kSeg3 flagged sub-bins
+      for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
+        const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
+        __syncthreads();
+        if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
+          Seg3 g;
+          g.pref = (s1.bin << 10) | (unsigned)tid;
+          g.next_pref = next_sub != kNoKey ? ((s1.bin << 10) | next_sub) : kNoKey;
+          g.cnt = c2;
+          g.r0 = r02;
+          g.p0 = p02;
+          lds->seg[ef2 - b3] = g;
+          lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
+        }
+        for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->hist3[0][0])[i] = 0u;
+        __syncthreads();
+        auto l3 = [&](unsigned key) {
+          const unsigned p = key >> L2_SHIFT;
+          for (unsigned j = 0; j < nseg; ++j) {
+            if (p == lds->seg[j].pref)
+              atomicAdd(&lds->hist3[j][key & (L3_BINS - 1)], 1u);
+            else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
+              atomicMin(&lds->succ3[j], key);
+          }
+        };
+        if (use_list) {
+          for (unsigned i = tid; i < list_n; i += kThreads) l3(lds->list[i]);
+        } else {
+          for_each_row_key(a, xrow, n, l3);
+        }
+        __syncthreads();
+        // wave j resolves segment j: lane owns 8 consecutive keys
+        if ((unsigned)wid < nseg) {
+          const Seg3 g = lds->seg[wid];
+          const unsigned succ_s = lds->succ3[wid];
+          unsigned kc[8];
+          unsigned lane_cnt = 0;
+          double lane_sum = 0.0;
+          unsigned first_key = kNoKey;
+#pragma unroll
+          for (int u = 7; u >= 0; --u) {
+            kc[u] = lds->hist3[wid][lane * 8 + u];
+            if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            lane_cnt += kc[u];
+            lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u));
+          }
+          const unsigned ic = wave_incl_scan(lane_cnt);
+          const double is = wave_incl_scan(lane_sum);
+          // next non-empty key after this lane's keys: suffix-min over higher lanes
+          unsigned after = kNoKey;
+          {
+            unsigned sm = first_key;   // suffix min including own lane
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const unsigned o = __shfl_down(sm, d);
+              if (lane + d < 64) sm = min(sm, o);
+            }
+            const unsigned up1 = __shfl_down(sm, 1);
+            after = lane < 63 ? up1 : kNoKey;
+          }
+          unsigned run_r0 = g.r0 + (ic - lane_cnt);
+          double run_p0 = g.p0 + (is - lane_sum);
+          // successor key of each own key
+          unsigned nextk[8];
+          unsigned cur = after != kNoKey ? after : succ_s;
+#pragma unroll
+          for (int u = 7; u >= 0; --u) {
+            nextk[u] = cur;
+            if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (kc[u]) {
+              const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+              const double v = (double)key_value(key);
+              const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
+              if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, lds->total, ternary)) {
+                Best c;
+                c.cost = cost_of(v, run_r0, run_p0, kc[u], n, lds->total, ternary);
+                c.order = run_r0;
+                c.value = key_value(key);
+                if (better(c, best)) best = c;
+                atomicAdd(&lds->n_cand, 1u);
+              }
+              run_r0 += kc[u];
+              run_p0 += (double)kc[u] * v;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
+  if (ternary && n > 0u && tid == 0) {
+    const double mean = lds->total / (double)n;
+    if ((double)key_value(minkey) > 0.5 * mean) {
+      const float half = (float)((double)((float)mean) / 2.0);
+      Best c;
+      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, lds->total, true);
+      c.order = n + 1u;
+      c.value = half;
+      if (better(c, best)) best = c;
+      atomicAdd(&lds->n_cand, 1u);
+    }
+  }
+
+  // ---- block argmin (first minimum in sorted order, optimal.py:151)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    Best o;
+    o.cost = __shfl_xor(best.cost, d);
+    o.order = __shfl_xor(best.order, d);
+    o.value = __shfl_xor(best.value, d);
+    if (better(o, best)) best = o;
+  }
+  __syncthreads();
+  if (lane == 0) lds->wbest[wid] = best;
+  __syncthreads();
+  Best r = lds->wbest[0];
+  for (int w = 1; w < kWaves; ++w)
+    if (better(lds->wbest[w], r)) r = lds->wbest[w];
+  *n_candidates = lds->n_cand;
+  return r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int VEC, bool SOLVER>
+__global__ __launch_bounds__(kThreads) void act_quant_kernel(Args a) {
+  using L = typename std::conditional<SOLVER, SolverLds, SmallLds>::type;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(L)];
+  L* lds = reinterpret_cast<L*>(smem);
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* xrow = a.x + (long long)row * a.row_elems;
+  const unsigned n_sub = (unsigned)((a.row_elems + a.skip - 1) / a.skip);
+
+  if (SOLVER) {
+    SolverLds* sl = reinterpret_cast<SolverLds*>(smem);
+    for (int i = tid; i < L1_BINS; i += kThreads) sl->hist1[i] = 0ull;
+  }
+  if (tid < LSQ_MAX_PLANES) lds->sv[tid] = a.forced ? (tid < a.k ? a.forced[(long long)tid * a.N + row] : 0.f) : 0.f;
+  __syncthreads();
+
+  Chain ch;
+  for (int q = 0; q < a.k; ++q) {
+    ch.q = q;
+#pragma unroll
+    for (int i = 0; i < LSQ_MAX_PLANES; ++i)
+      ch.v[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lds->sv[i])));
+    double part = 0.0;
+    unsigned mk = kNoKey;
+    const bool hist = SOLVER && q == 0 && !a.forced;
+    unsigned long long* prow = a.flat ? nullptr : a.planes + (long long)q * a.plane_words + (long long)row * a.row_words;
+    if (a.flat) {
+      if (q == 0) {
+        if (hist) flat_pass<SOLVER, 0>(a, xrow, ch, part, mk, lds);
+        else flat_pass<false, 0>(a, xrow, ch, part, mk, lds);
+      } else if (q == 1) {
+        flat_pass<false, 1>(a, xrow, ch, part, mk, lds);
+      } else {
+        flat_pass<false, 2>(a, xrow, ch, part, mk, lds);
+      }
+    } else {
+      if (q == 0) {
+        if (hist) pack_pass<VEC, SOLVER, 0>(a, xrow, prow, ch, part, mk, lds);
+        else pack_pass<VEC, false, 0>(a, xrow, prow, ch, part, mk, lds);
+      } else if (q == 1) {
+        pack_pass<VEC, false, 1>(a, xrow, prow, ch, part, mk, lds);
+      } else {
+        pack_pass<VEC, false, 2>(a, xrow, prow, ch, part, mk, lds);
+      }
+    }
+    const double tot = block_sum(part, lds);
+    float vq = (float)(tot / (double)a.row_elems);
+    if (SOLVER) {
+      if (q == 0 && !a.forced) {
+        SolverLds* sl = reinterpret_cast<SolverLds*>(smem);
+        mk = wave_min(mk);
+        __syncthreads();
+        if ((tid & 63) == 0) sl->wa[tid >> 6] = mk;
+        __syncthreads();
+        unsigned minkey = kNoKey;
+        for (int w = 0; w < kWaves; ++w) minkey = min(minkey, sl->wa[w]);
+        unsigned ncand = 0;
+        vq = solve_v1(a, xrow, n_sub, minkey, sl, &ncand);
+        if (a.status && tid == 0) a.status[row] = (int)ncand;
+      }
+      if (q == 1 && a.scheme == LSQ_SCHEME_LST) vq = lds->sv[0];
+    }
+    __syncthreads();
+    if (tid == 0 && !a.forced) lds->sv[q] = vq;
+    __syncthreads();
+  }
+  if (tid < a.k) {
+    if (a.scales) a.scales[(long long)tid * a.N + row] = lds->sv[tid];
+  }
+}
+
+template <int VEC>
+int launch(const Args& a, bool solver, hipStream_t st) {
+  if (solver) hipLaunchKernelGGL((act_quant_kernel<VEC, true>), dim3(a.N), dim3(kThreads), 0, st, a);
+  else hipLaunchKernelGGL((act_quant_kernel<VEC, false>), dim3(a.N), dim3(kThreads), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+}  // namespace lsq
+
+using namespace lsq;
+
+extern "C" int64_t lsq_act_plane_words(const lsq_conv_geom* g) {
+  if (check_geom(g)) return -1;
+  const int64_t cg = g->C / g->groups, Gg = (cg + 63) / 64;
+  return (int64_t)g->N * g->groups * Gg * (g->H + 2 * g->pad_h) * (g->W + 2 * g->pad_w);
+}
+
+extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
+                             float clamp_alpha, const float* forced, uint64_t* planes, float* scales,
+                             void* stream) {
+  if (!x || !planes || !scales) return LSQ_E_NULL;
+  if (int e = check_geom(g)) return e;
+  if (skip < 1) return LSQ_E_SHAPE;
+  if (k < 1 || k > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
+  if ((scheme == LSQ_SCHEME_LS1 && k != 1) || ((scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && k != 2) ||
+      scheme < LSQ_SCHEME_LS1 || scheme > LSQ_SCHEME_GF)
+    return LSQ_E_SCHEME;
+  Args a = {};
+  a.x = x;
+  a.C = g->C; a.H = g->H; a.W = g->W;
+  a.row_elems = (long long)g->C * g->H * g->W;
+  a.cg = g->C / g->groups;
+  a.Gg = (a.cg + 63) / 64;
+  a.Gt = g->groups * a.Gg;
+  a.pad_h = g->pad_h; a.pad_w = g->pad_w;
+  a.Hp = g->H + 2 * g->pad_h; a.Wp = g->W + 2 * g->pad_w;
+  a.scheme = scheme; a.k = k; a.skip = skip; a.alpha = clamp_alpha;
+  a.forced = forced;
+  a.planes = (unsigned long long*)planes;
+  a.row_words = (long long)a.Gt * a.Hp * a.Wp;
+  a.plane_words = a.row_words * g->N;
+  a.scales = scales;
+  a.N = g->N;
+  a.ternary = scheme == LSQ_SCHEME_LST;
+  const bool solver = (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && !forced;
+  if (solver && (a.row_elems + skip - 1) / skip >= (1ll << 22)) return LSQ_E_TOO_LONG;
+  const int HW = g->H * g->W;
+  const bool al16 = ((uintptr_t)x % 16) == 0, al8 = ((uintptr_t)x % 8) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (HW % 4 == 0 && al16 && (long long)a.Gt * (HW / 4) >= 512) return launch<4>(a, solver, st);
+  if (HW % 2 == 0 && al8 && (long long)a.Gt * (HW / 2) >= 512) return launch<2>(a, solver, st);
+  return launch<1>(a, solver, st);
+}
+
+extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,
+                              float clamp_alpha, float* v12, int32_t* status, void* stream) {
+  if (!rows || !v12) return LSQ_E_NULL;
+  if (R <= 0 || M <= 0 || skip < 1 || R > 0x7FFFFFFF) return LSQ_E_SHAPE;
+  if ((M + skip - 1) / skip >= (1ll << 22)) return LSQ_E_TOO_LONG;
+  Args a = {};
+  a.x = rows;
+  a.row_elems = M;
+  a.C = 1; a.H = 1; a.W = 1; a.cg = 1; a.Gg = 1; a.Gt = 1; a.Hp = 1; a.Wp = 1;
+  a.scheme = ternary ? LSQ_SCHEME_LST : LSQ_SCHEME_LS2;
+  a.k = 2;
+  a.skip = skip;
+  a.alpha = clamp_alpha;
+  a.N = (int)R;
+  a.flat = 1;
+  a.ternary = ternary ? 1 : 0;
+  a.status = status;
+  a.scales = v12;
+  return launch<1>(a, true, (hipStream_t)stream);
+}

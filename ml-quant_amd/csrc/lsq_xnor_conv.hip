@@ -1,0 +1,176 @@
+// Binary x binary convolution for gfx950: XNOR + popcount over channel-packed 64-bit words.
+//
+// Replaces F.conv2d(x_q, w_q, ...) of quant/binary/binary_conv.py:165-173 when both operands
+// are sums of scaled sign planes.  For planes b_p (activation) and s_q (weight)
+//     (b_p (*) s_q)[n,o,y,x] = sum_{taps, c} b*s = cg*taps - 2*popcount(b XOR s)   (exact integer)
+// so the whole fp32 convolution collapses to integer popcounts plus a tiny fp32 epilogue.
+//
+// Mapping: one lane = one output pixel, OT output channels per lane held in registers.  The
+// lanes of a wave walk consecutive pixels, so activation words are coalesced 8-byte loads
+// that hit L1/L2 (a whole layer's bit planes are a few MB); every lane of a wave needs the
+// SAME weight words, so they are wave-uniform and come through the scalar cache into SGPRs:
+// the inner loop is v_xor_b32 + v_bcnt_u32_b32 on a VGPR and an SGPR operand, two VALU ops
+// per 32 binary MACs -- the VALU popcount roofline of SURVEY.md section 8(d).
+//
+// Zero padding: the bit planes carry a physical halo of zero words (= all -1).  A padded tap
+// therefore contributes -sum_c s[o][c][tap] instead of 0; the epilogue adds wsum[o][tap] back
+// for every out-of-image tap of a border pixel, which makes the result exact.
+
+#include "lsq_common.h"
+
+namespace lsq {
+namespace {
+
+struct ConvArgs {
+  const unsigned long long* xplanes;   // [KX][N][Gt][Hp][Wp]
+  const float* xscales;                // [KX][N]
+  const unsigned long long* wbits;     // [taps][Gg][Opad]  (one weight plane)
+  const int* wsum;                     // [O][taps]
+  const float* wscale;                 // [O]
+  const float* bias;                   // [O] or null
+  float* y;                            // [N][O][Ho][Wo]
+  long long xplane_words;
+  int N, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
+  int Gg, Gt, Hp, Wp, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
+  int accumulate;
+};
+
+template <int KX, int OT>
+__global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)a.N * a.Ho * a.Wo;
+  if (pix >= total) return;
+  const int tile = blockIdx.y;
+  const int grp = tile / a.tiles_per_group;
+  const int t = tile - grp * a.tiles_per_group;
+  const int o_pad0 = grp * a.og_pad + t * OT;
+  const int o0 = grp * a.og + t * OT;
+  const int o_valid = min(OT, a.og - t * OT);
+  const int HoWo = a.Ho * a.Wo;
+  const int n = (int)(pix / HoWo);
+  const int r = (int)(pix - (long long)n * HoWo);
+  const int ho = r / a.Wo, wo = r - ho * a.Wo;
+  const long long HpWp = (long long)a.Hp * a.Wp;
+
+  int acc[KX][OT];
+#pragma unroll
+  for (int p = 0; p < KX; ++p)
+#pragma unroll
+    for (int o = 0; o < OT; ++o) acc[p][o] = 0;
+
+  const unsigned long long* __restrict__ xp =
+      a.xplanes + ((long long)n * a.Gt + (long long)grp * a.Gg) * HpWp + (long long)(ho * a.sh) * a.Wp + wo * a.sw;
+  const unsigned long long* __restrict__ wbase = a.wbits + o_pad0;
+
+  for (int j = 0; j < a.Gg; ++j) {
+    for (int kh = 0; kh < a.KH; ++kh) {
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const long long off = (long long)j * HpWp + (long long)(kh * a.dh) * a.Wp + kw * a.dw;
+        unsigned long long xa[KX];
+#pragma unroll
+        for (int p = 0; p < KX; ++p) xa[p] = xp[(long long)p * a.xplane_words + off];
+        const unsigned long long* __restrict__ wp = wbase + ((long long)(kh * a.KW + kw) * a.Gg + j) * a.opad_total;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          const unsigned long long wv = wp[o];
+#pragma unroll
+          for (int p = 0; p < KX; ++p) acc[p][o] += __popcll(xa[p] ^ wv);
+        }
+      }
+    }
+  }
+
+  // border correction: out-of-image taps were computed against zero words
+  const int taps = a.KH * a.KW;
+  int corr[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) corr[o] = 0;
+  const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+  const bool border = hi0 < 0 || wi0 < 0 || hi0 + (a.KH - 1) * a.dh >= a.H || wi0 + (a.KW - 1) * a.dw >= a.W;
+  if (border) {
+    for (int kh = 0; kh < a.KH; ++kh) {
+      for (int kw = 0; kw < a.KW; ++kw) {
+        const int hi = hi0 + kh * a.dh, wi = wi0 + kw * a.dw;
+        if (hi < 0 || hi >= a.H || wi < 0 || wi >= a.W) {
+#pragma unroll
+          for (int o = 0; o < OT; ++o)
+            if (o < o_valid) corr[o] += a.wsum[(long long)(o0 + o) * taps + kh * a.KW + kw];
+        }
+      }
+    }
+  }
+
+  float xs[KX];
+#pragma unroll
+  for (int p = 0; p < KX; ++p) xs[p] = a.xscales[(long long)p * a.N + n];
+  const int full = a.cg * taps;
+  float* yp = a.y + ((long long)n * a.O + o0) * HoWo + r;
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    if (o < o_valid) {
+      float v = 0.f;
+#pragma unroll
+      for (int p = 0; p < KX; ++p) v += xs[p] * (float)(full - 2 * acc[p][o] + corr[o]);
+      v *= a.wscale[o0 + o];
+      const float base = a.accumulate ? yp[(long long)o * HoWo] : (a.bias ? a.bias[o0 + o] : 0.f);
+      yp[(long long)o * HoWo] = base + v;
+    }
+  }
+}
+
+template <int KX>
+int launch_kx(const ConvArgs& a, int groups, hipStream_t st) {
+  const long long total = (long long)a.N * a.Ho * a.Wo;
+  dim3 grid((unsigned)((total + 255) / 256), (unsigned)(groups * a.tiles_per_group));
+  hipLaunchKernelGGL((xnor_conv_kernel<KX, 16>), grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+}  // namespace lsq
+
+using namespace lsq;
+
+extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
+                               const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
+                               const lsq_conv_geom* g, float* y, void* stream) {
+  if (!xplanes || !xscales || !wbits || !wsum || !wscales || !y) return LSQ_E_NULL;
+  if (int e = check_geom(g)) return e;
+  if (kx < 1 || kx > LSQ_MAX_PLANES || kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
+  const int Ho = out_h(g), Wo = out_w(g);
+  if (Ho <= 0 || Wo <= 0) return LSQ_E_SHAPE;
+  ConvArgs a = {};
+  a.N = g->N; a.H = g->H; a.W = g->W; a.O = g->O; a.KH = g->KH; a.KW = g->KW;
+  a.sh = g->stride_h; a.sw = g->stride_w; a.ph = g->pad_h; a.pw = g->pad_w; a.dh = g->dil_h; a.dw = g->dil_w;
+  a.cg = g->C / g->groups;
+  a.Gg = (a.cg + 63) / 64;
+  a.Gt = g->groups * a.Gg;
+  a.Hp = g->H + 2 * g->pad_h; a.Wp = g->W + 2 * g->pad_w;
+  a.Ho = Ho; a.Wo = Wo;
+  a.og = g->O / g->groups;
+  a.og_pad = (a.og + 15) / 16 * 16;
+  a.opad_total = g->groups * a.og_pad;
+  a.tiles_per_group = a.og_pad / 16;
+  a.xplane_words = lsq_act_plane_words(g);
+  a.bias = bias;
+  a.y = y;
+  const long long wplane_words = lsq_weight_plane_words(g);
+  const int taps = g->KH * g->KW;
+  hipStream_t st = (hipStream_t)stream;
+  bool first = true;
+  for (int q = 0; q < kw_planes; ++q) {
+    for (int p0 = 0; p0 < kx; p0 += 2) {
+      const int np = (kx - p0) >= 2 ? 2 : 1;
+      a.xplanes = (const unsigned long long*)xplanes + (long long)p0 * a.xplane_words;
+      a.xscales = xscales + (long long)p0 * g->N;
+      a.wbits = (const unsigned long long*)wbits + (long long)q * wplane_words;
+      a.wsum = wsum + (long long)q * g->O * taps;
+      a.wscale = wscales + (long long)q * g->O;
+      a.accumulate = first ? 0 : 1;
+      const int e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
+      if (e) return e;
+      first = false;
+    }
+  }
+  return LSQ_OK;
+}

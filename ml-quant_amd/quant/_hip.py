@@ -1,0 +1,163 @@
+"""ctypes binding of the gfx950 C-ABI library (``include/lsq_hip.h``).
+
+PyTorch is used only as the owner of device memory and streams: every call passes raw
+device pointers (``tensor.data_ptr()``) and the current HIP stream.  There is no CPU or
+eager fallback here: if the library is missing, or a call fails, an exception is raised.
+"""
+
+import ctypes
+import os
+import threading
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'liblsq_hip.so')
+_lock = threading.Lock()
+_lib = None
+
+SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
+MAX_PLANES = 8
+
+
+class ConvGeom(ctypes.Structure):
+    """Mirror of ``lsq_conv_geom``."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'N', 'C', 'H', 'W', 'O', 'KH', 'KW', 'stride_h', 'stride_w',
+        'pad_h', 'pad_w', 'dil_h', 'dil_w', 'groups')]
+
+    def key(self):
+        return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+class LsqHipError(RuntimeError):
+    """A C-ABI call returned a non-zero code."""
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def _declare(lib):
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    gp = ctypes.POINTER(ConvGeom)
+    lib.lsq_abi_version.restype = i32
+    lib.lsq_error_string.restype = ctypes.c_char_p
+    lib.lsq_error_string.argtypes = [i32]
+    lib.lsq_act_plane_words.restype = i64
+    lib.lsq_act_plane_words.argtypes = [gp]
+    lib.lsq_weight_plane_words.restype = i64
+    lib.lsq_weight_plane_words.argtypes = [gp]
+    lib.lsq_act_quant.restype = i32
+    lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp]
+    lib.lsq_solve_rows.restype = i32
+    lib.lsq_solve_rows.argtypes = [vp, i64, i64, i32, i32, f32, vp, vp, vp]
+    lib.lsq_pack_weight.restype = i32
+    lib.lsq_pack_weight.argtypes = [vp, gp, i32, vp, vp, vp, vp]
+    lib.lsq_xnor_conv2d.restype = i32
+    lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, vp, vp]
+    lib.lsq_signw_conv2d.restype = i32
+    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, i32, vp, vp, gp, vp, vp]
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(_LIB_PATH):
+                    raise LsqHipError(
+                        f'{_LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(or `make -C ml-quant_amd/csrc`). The HIP path has no fallback.')
+                handle = ctypes.CDLL(_LIB_PATH)
+                _declare(handle)
+                if handle.lsq_abi_version() != 1:
+                    raise LsqHipError('liblsq_hip.so ABI version mismatch')
+                _lib = handle
+    return _lib
+
+
+def available() -> bool:
+    return os.path.exists(_LIB_PATH)
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().lsq_error_string(code).decode()
+        raise LsqHipError(f'{what} failed with code {code}: {msg}')
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def make_geom(n, c, h, w, o, kh, kw, stride, padding, dilation, groups) -> ConvGeom:
+    return ConvGeom(n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1],
+                    dilation[0], dilation[1], groups)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f'the HIP path computes in fp32, got {t.dtype}')
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, alpha: float,
+              planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None) -> None:
+    x = _f32c(x)
+    check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha), ptr(forced),
+                              planes.data_ptr(), scales.data_ptr(), stream_ptr()), 'lsq_act_quant')
+
+
+def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0):
+    """Returns (v12 [2,R] fp32, status [R] int32)."""
+    rows = _f32c(rows)
+    r, m = rows.shape
+    v12 = torch.empty((2, r), dtype=torch.float32, device=rows.device)
+    status = torch.empty((r,), dtype=torch.int32, device=rows.device)
+    check(lib().lsq_solve_rows(rows.data_ptr(), r, m, skip, int(ternary), float(alpha), v12.data_ptr(),
+                               status.data_ptr(), stream_ptr()), 'lsq_solve_rows')
+    return v12, status
+
+
+def pack_weight(w: torch.Tensor, geom: ConvGeom, scales: torch.Tensor):
+    """scales [k, O] -> (wbits int64 [k * words], wsum int32 [k, O, taps])."""
+    w = _f32c(w)
+    scales = _f32c(scales)
+    k = scales.shape[0]
+    words = lib().lsq_weight_plane_words(ctypes.byref(geom))
+    wbits = torch.empty((k * words,), dtype=torch.int64, device=w.device)
+    wsum = torch.empty((k, geom.O, geom.KH * geom.KW), dtype=torch.int32, device=w.device)
+    check(lib().lsq_pack_weight(w.data_ptr(), ctypes.byref(geom), k, scales.data_ptr(), wbits.data_ptr(),
+                                wsum.data_ptr(), stream_ptr()), 'lsq_pack_weight')
+    return wbits, wsum
+
+
+def act_plane_words(geom: ConvGeom) -> int:
+    return lib().lsq_act_plane_words(ctypes.byref(geom))
+
+
+def out_hw(geom: ConvGeom):
+    ho = (geom.H + 2 * geom.pad_h - geom.dil_h * (geom.KH - 1) - 1) // geom.stride_h + 1
+    wo = (geom.W + 2 * geom.pad_w - geom.dil_w * (geom.KW - 1) - 1) // geom.stride_w + 1
+    return ho, wo
+
+
+def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: torch.Tensor, wsum: torch.Tensor,
+                wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
+    check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
+                                wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(),
+                                stream_ptr()), 'lsq_xnor_conv2d')
+
+
+def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,
+                 bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
+    x = _f32c(x)
+    check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), wbits.data_ptr(), wscales.shape[0], wscales.data_ptr(),
+                                 ptr(bias), ctypes.byref(geom), y.data_ptr(), stream_ptr()), 'lsq_signw_conv2d')

@@ -1,0 +1,183 @@
+"""``QuantConv2d``: 2-D convolution of scaled-binary-quantized activations and weights.
+
+Drop-in for the reference's ``quant/binary/binary_conv.py`` (:48-173): same constructor
+(positional ``x_quant, w_quant, in_channels, out_channels, kernel_size, clamp,
+moving_average_mode, moving_average_momentum`` then ``nn.Conv2d`` kwargs), same attributes
+(``x_approximate``, ``w_approximate``, ``clamping_fn``, ``quantized_parameters``), same
+``state_dict`` keys and the same ``ValueError`` on bad schemes / clamp kinds.
+
+Dispatch of ``forward``:
+  * CUDA (ROCm) tensor, ``eval()`` mode, no gradient wanted for the input -> gfx950 kernels via
+    the C ABI (``quant._hip``): clamp + per-sample scale solve + sign packing in one kernel,
+    then an XNOR-popcount convolution (binary activations) or a bf16-MFMA convolution
+    (fp activations) against weight sign planes packed once per ``eval()`` session.  There is
+    no fallback on this branch: a missing library or a failed launch raises.
+  * anything else (CPU tensors, training) -> the torch formulation in ``quant.binary``.
+"""
+
+import re
+from collections import defaultdict
+from functools import partial
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import quant.binary.activation_quantization as activation_quantization
+import quant.binary.quantization as quantization
+import quant.binary.weight_quantization as weight_quantization
+
+_SCHEME_RE = re.compile(r'fp|ls-1|ls-2|ls-T|gf-\d+')
+
+
+class QuantConv2d(nn.Conv2d):
+    """``Conv2d(x_quant(clamp(x)), w_quant(w))`` with schemes fp | ls-1 | ls-2 | ls-T | gf-k."""
+
+    #: sub-sampling stride of the activation v1 search (quantizer_ls_2 / ls_ternary default)
+    act_skip = 3
+
+    def __init__(self, x_quant: str, w_quant: str, in_channels: int, out_channels: int,
+                 kernel_size: Union[int, Tuple[int, int]], clamp: Optional[Dict] = None,
+                 moving_average_mode: str = 'off', moving_average_momentum: float = 0.99,
+                 **kwargs: Any) -> None:
+        super().__init__(in_channels, out_channels, kernel_size, **kwargs)
+        self.x_quant, self.w_quant = x_quant, w_quant
+        self.x_approximate = self._get_x_quantizer(x_quant, moving_average_mode, moving_average_momentum)
+        self.w_approximate = self._get_w_quantizer(w_quant, out_channels)
+        self.clamp_config = dict(clamp) if clamp is not None else {'kind': 'identity'}
+        self.clamping_fn = self._get_clamper(**self.clamp_config)
+
+        self.quantized_parameters: Dict[str, List[torch.Tensor]] = defaultdict(list)
+        if self.bias is not None:
+            self.quantized_parameters['fp'].append(self.bias)
+        self.quantized_parameters[w_quant].append(self.weight)
+
+        self._hip_cache: Dict[str, Any] = {}          # packed weights, workspaces (never in state_dict)
+
+    # ------------------------------------------------------------------ factories
+    @staticmethod
+    def _validate_scheme(scheme: str) -> None:
+        if not isinstance(scheme, str) or not _SCHEME_RE.fullmatch(scheme):
+            raise ValueError(f'Scheme {scheme} is invalid. Please see docs for valid schemes.')
+
+    @staticmethod
+    def _get_x_quantizer(scheme: str, moving_average_mode: str = 'off',
+                         moving_average_momentum: float = 0.99) -> nn.Module:
+        QuantConv2d._validate_scheme(scheme)
+        if scheme == 'fp':
+            return quantization.QuantizerFP()
+        if scheme.startswith('gf-'):
+            return activation_quantization.ActivationQuantizerGF(
+                int(scheme[3:]), moving_average_mode, moving_average_momentum)
+        cls = {'ls-1': activation_quantization.ActivationQuantizerLS1,
+               'ls-2': activation_quantization.ActivationQuantizerLS2,
+               'ls-T': activation_quantization.ActivationQuantizerLST}[scheme]
+        return cls(moving_average_mode, moving_average_momentum)
+
+    @staticmethod
+    def _get_w_quantizer(scheme: str, size: int) -> nn.Module:
+        QuantConv2d._validate_scheme(scheme)
+        if scheme == 'fp':
+            return quantization.QuantizerFP()
+        if scheme.startswith('gf-'):
+            return weight_quantization.WeightQuantizerGF(size, int(scheme[3:]))
+        cls = {'ls-1': weight_quantization.WeightQuantizerLS1,
+               'ls-2': weight_quantization.WeightQuantizerLS2,
+               'ls-T': weight_quantization.WeightQuantizerLST}[scheme]
+        return cls(size)
+
+    @staticmethod
+    def _get_clamper(kind: str, alpha: float = 2) -> Callable[[torch.Tensor], torch.Tensor]:
+        if kind == 'identity':
+            return quantization.clamp_identity
+        if kind == 'symmetric':
+            return partial(quantization.clamp_symmetric, alpha=alpha)
+        raise ValueError(f'{kind} is not a valid clamping function.')
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._wants_hip(x):
+            return self._forward_hip(x)
+        return self._forward_torch(x)
+
+    def _forward_torch(self, x: torch.Tensor) -> torch.Tensor:
+        x_q = self.x_approximate(self.clamping_fn(x))
+        w_q = self.w_approximate(self.weight)
+        return F.conv2d(x_q, w_q, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+    def _wants_hip(self, x: torch.Tensor) -> bool:
+        if not x.is_cuda or self.training:
+            return False
+        if torch.is_grad_enabled() and x.requires_grad:
+            return False
+        if self.padding_mode != 'zeros' or isinstance(self.padding, str) or x.dim() != 4:
+            return False
+        if self.w_quant == 'fp':          # nothing binary on the weight side: plain conv
+            return False
+        return True
+
+    def train(self, mode: bool = True):
+        if mode:
+            self._hip_cache.clear()       # weights (and cached scales) may change
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._hip_cache.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._hip_cache.clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    # ------------------------------------------------------------------ HIP path
+    def _alpha(self) -> float:
+        if self.clamp_config.get('kind') == 'symmetric':
+            return float(self.clamp_config.get('alpha', 2))
+        return -1.0
+
+    def _packed_weights(self, geom, _hip):
+        wq = self.w_approximate
+        bufs = wq.cached_scales()
+        stamp = (self.weight._version, self.weight.data_ptr(), tuple(b._version for b in bufs),
+                 tuple(b.data_ptr() for b in bufs), geom.key()[4:])
+        hit = self._hip_cache.get('w')
+        if hit is None or hit[0] != stamp:
+            scales = wq.plane_scales().to(torch.float32).contiguous()
+            wbits, wsum = _hip.pack_weight(self.weight.detach(), geom, scales)
+            hit = (stamp, wbits, wsum, scales)
+            self._hip_cache['w'] = hit
+        return hit[1], hit[2], hit[3]
+
+    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+        from quant import _hip
+        x = x.detach()
+        n, c, h, w = x.shape
+        kh, kw = self.kernel_size
+        geom = _hip.make_geom(n, c, h, w, self.out_channels, kh, kw, self.stride, self.padding,
+                              self.dilation, self.groups)
+        wbits, wsum, wscales = self._packed_weights(geom, _hip)
+        ho, wo = _hip.out_hw(geom)
+        y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
+        bias = None if self.bias is None else self.bias.detach()
+        if self.x_quant == 'fp':
+            _hip.signw_conv2d(self.clamping_fn(x), -1.0, wbits, wscales, bias, geom, y)
+            return y
+        xq = self.x_approximate
+        k = xq.n_planes
+        key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device)
+        ws = self._hip_cache.get(key)
+        if ws is None:
+            words = _hip.act_plane_words(geom)
+            # halo words must be zero; the kernels only ever write the interior
+            ws = (torch.zeros((k * words,), dtype=torch.int64, device=x.device),
+                  torch.empty((k, n), dtype=torch.float32, device=x.device))
+            self._hip_cache[key] = ws
+        planes, scales = ws
+        forced = xq.eval_scales(n)
+        if forced is not None:
+            forced = forced.to(device=x.device, dtype=torch.float32).contiguous()
+        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced)
+        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y)
+        self.last_act_scales = scales
+        return y

@@ -1,0 +1,105 @@
+"""Optimal first scale of the 2-bit / ternary least-squares quantizers (host implementation).
+
+Same contract as the reference's ``quant/binary/optimal.py`` (``opt_v1`` :121-155,
+``compute_mask`` :41-83, ``cost_function`` :16-38) but stated the way the gfx950 solver
+computes it (``csrc/lsq_act_quant.hip``): prefix sums are carried in fp64 and a candidate's
+cost is evaluated in closed form from them, O(M log M) per row with no [N, K, M] temporary.
+CUDA tensors go to the HIP solver; this torch formulation serves CPU tensors and autograd.
+"""
+
+from typing import Tuple
+
+import torch
+
+from quant.binary.ste import binary_sign
+
+
+def _prefix(matrix: torch.Tensor):
+    values, _ = torch.sort(matrix, dim=1)
+    run = values.to(torch.float64).cumsum(dim=1)
+    return values, run
+
+
+def compute_mask(matrix: torch.Tensor, ternary: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Candidate mask over inner sorted positions of a matrix of absolute values.
+
+    Position i (1 <= i <= L-2) is kept when half the mean of the elements above it, or (2-bit
+    case) the average of the means below-and-including / above it, lies in [a_i, a_{i+1}].
+    Returns (mask [N, L-2], selected values as a flat vector).
+    """
+    values, run = _prefix(matrix)
+    n = matrix.shape[1]
+    idx = torch.arange(1, n - 1, device=matrix.device)
+    lo_cnt = (idx + 1).to(torch.float64)
+    hi_cnt = (n - 1 - idx).to(torch.float64)
+    v64 = values.to(torch.float64)
+    hi_mean = (run[:, -1:] - run[:, 1:-1]) / hi_cnt
+    left, right = v64[:, 1:-1], v64[:, 2:]
+    half = 0.5 * hi_mean
+    mask = (left <= half) & (half <= right)
+    if not ternary:
+        mid = 0.5 * (run[:, 1:-1] / lo_cnt + hi_mean)
+        mask = mask | ((left <= mid) & (mid <= right))
+    return mask, torch.masked_select(values[:, 1:-1], mask)
+
+
+def cost_function(matrix: torch.Tensor, v1s: torch.Tensor, ternary: bool = False) -> torch.Tensor:
+    """||(a - v1) - v2 sign(a - v1)||_2 per (row, candidate), v2 = mean|a - v1| (or v1 if ternary).
+
+    ``matrix`` [N, L] holds absolute values, ``v1s`` [N, K] candidates; closed form via prefix sums.
+    """
+    sq = (matrix.to(torch.float64) ** 2).sum(dim=1, keepdim=True)
+    return (_cost_sq(matrix, v1s, ternary) + sq).clamp_min(0).sqrt().to(matrix.dtype)
+
+
+def _opt_v1_torch(matrix_skipped: torch.Tensor, ternary: bool) -> torch.Tensor:
+    a = matrix_skipped
+    rows, n = a.shape
+    out = a.new_zeros((rows, 1))
+    if n < 3 and not ternary:
+        return out
+    mask, _ = compute_mask(a, ternary) if n >= 3 else (a.new_zeros((rows, 0), dtype=torch.bool), None)
+    values, _ = torch.sort(a, dim=1)
+    inner = values[:, 1:-1] if n >= 3 else values[:, :0]
+    big = torch.finfo(torch.float64).max
+    if inner.shape[1] > 0:
+        costs = _cost_sq(a, inner, ternary)      # squared cost minus a per-row constant
+        costs = torch.where(mask, costs, torch.full_like(costs, big))
+        best_cost, best_idx = costs.min(dim=1, keepdim=True)
+        found = mask.any(dim=1, keepdim=True)
+        out = torch.where(found, torch.gather(inner, 1, best_idx), out)
+    else:
+        best_cost = a.new_full((rows, 1), big, dtype=torch.float64)
+        found = torch.zeros((rows, 1), dtype=torch.bool, device=a.device)
+    if ternary:
+        mean = a.to(torch.float64).mean(dim=1, keepdim=True)
+        low = a.min(dim=1, keepdim=True).values.to(torch.float64)
+        extra = low > 0.5 * mean
+        half = (mean.to(a.dtype).to(torch.float64) / 2).to(a.dtype)
+        extra_cost = _cost_sq(a, half, True)
+        take = extra & (~found | (extra_cost < best_cost))
+        out = torch.where(take, half, out)
+    return out
+
+
+def _cost_sq(matrix: torch.Tensor, v1s: torch.Tensor, ternary: bool) -> torch.Tensor:
+    values, run = _prefix(matrix)
+    n = matrix.shape[1]
+    v64 = values.to(torch.float64)
+    cand = v1s.to(torch.float64)
+    total = run[:, -1:]
+    below = torch.searchsorted(v64.contiguous(), cand.contiguous(), right=False)
+    below_sum = torch.gather(torch.cat([torch.zeros_like(total), run], dim=1), 1, below)
+    dev = (cand * below - below_sum) + ((total - below_sum) - cand * (n - below))
+    quad = -2.0 * cand * total + n * cand * cand           # minus the constant sum a^2
+    return quad - 2.0 * cand * dev + n * cand * cand if ternary else quad - dev * dev / n
+
+
+def opt_v1(matrix: torch.Tensor, ternary: bool, skip: int = 1) -> torch.Tensor:
+    """Optimal v1 per row of a 2-D tensor, searched over every ``skip``-th element. Returns [N, 1]."""
+    with torch.no_grad():
+        if matrix.is_cuda:
+            from quant import _hip
+            v12, _ = _hip.solve_rows(matrix, skip, ternary)
+            return v12[0].view(-1, 1)
+        return _opt_v1_torch(matrix[..., ::skip].abs(), ternary)

@@ -1,0 +1,149 @@
+"""ResNet with quantized 3x3 convolutions (regular and XNOR-style basic blocks).
+
+Constructor arguments, sub-module names (hence ``state_dict`` keys) and error behaviour follow
+the reference's ``quant/models/resnet.py`` (``RegularBasicBlock`` :27-101, ``XnorBasicBlock``
+:104-190, ``QResNet`` :193-397) so its yaml ``arch_config`` sections and checkpoints drop in.
+The stem, the 1x1 shortcuts, batch norms, non-linearities and the classifier are full
+precision and stay on stock PyTorch-ROCm ops; every 3x3 convolution of the residual blocks is
+a ``QuantConv2d`` and, in eval mode on the GPU, runs on the gfx950 kernels.
+"""
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from quant.binary.binary_conv import QuantConv2d
+
+non_linearity_map = {'relu': nn.ReLU, 'prelu': nn.PReLU, 'identity': nn.Identity}
+
+
+def _check_nonlins(nonlins: List[str]) -> None:
+    if len(nonlins) != 2:
+        raise ValueError('There should be 2 non-linearities.')
+
+
+def _projection(in_planes: int, planes: int, stride: int, bias: bool) -> nn.Sequential:
+    """Full-precision down-sampling shortcut (empty when shapes already agree)."""
+    if stride == 1 and in_planes == planes:
+        return nn.Sequential()
+    return nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride, bias=bias),
+                         nn.BatchNorm2d(planes))
+
+
+def _qconv(x_quant, w_quant, cin, cout, clamp, mode, momentum, stride, bias):
+    return QuantConv2d(x_quant, w_quant, cin, cout, 3, clamp, mode, momentum,
+                       stride=stride, padding=1, bias=bias)
+
+
+class RegularBasicBlock(nn.Module):
+    """conv-bn-nonlin, conv-bn, add shortcut, nonlin."""
+
+    def __init__(self, in_planes: int, planes: int, x_quant: str, w_quant: str, nonlins: List[str],
+                 stride: int = 1, clamp: Optional[Dict] = None, moving_average_mode: str = 'off',
+                 moving_average_momentum: float = 0.99) -> None:
+        super().__init__()
+        _check_nonlins(nonlins)
+        mode, mom = moving_average_mode, moving_average_momentum
+        self.conv1 = _qconv(x_quant, w_quant, in_planes, planes, clamp, mode, mom, stride, False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.nonlin1 = non_linearity_map[nonlins[0]]()
+        self.conv2 = _qconv(x_quant, w_quant, planes, planes, clamp, mode, mom, 1, False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.nonlin2 = non_linearity_map[nonlins[1]]()
+        self.shortcut = _projection(in_planes, planes, stride, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.nonlin1(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y)) + self.shortcut(x)
+        return self.nonlin2(y)
+
+
+class XnorBasicBlock(nn.Module):
+    """bn-quantconv-nonlin twice (XNOR-Net ordering), optionally with Bi-Real double shortcuts."""
+
+    def __init__(self, in_planes: int, planes: int, x_quant: str, w_quant: str, nonlins: List[str],
+                 stride: int = 1, double_shortcut: bool = False, clamp: Optional[Dict] = None,
+                 moving_average_mode: str = 'off', moving_average_momentum: float = 0.99) -> None:
+        super().__init__()
+        _check_nonlins(nonlins)
+        mode, mom = moving_average_mode, moving_average_momentum
+        self.double_shortcut = double_shortcut
+        self.bn1 = nn.BatchNorm2d(in_planes)
+        self.conv1 = _qconv(x_quant, w_quant, in_planes, planes, clamp, mode, mom, stride, True)
+        self.nonlin1 = non_linearity_map[nonlins[0]]()
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv2 = _qconv(x_quant, w_quant, planes, planes, clamp, mode, mom, 1, True)
+        self.nonlin2 = non_linearity_map[nonlins[1]]()
+        self.shortcut = _projection(in_planes, planes, stride, bias=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        first = self.nonlin1(self.conv1(self.bn1(x)))
+        if self.double_shortcut:
+            first = first + self.shortcut(x)
+            return self.nonlin2(self.conv2(self.bn2(first))) + first
+        second = self.conv2(self.bn2(first)) + self.shortcut(x)
+        return self.nonlin2(second)
+
+
+_BLOCKS = {'regular': RegularBasicBlock, 'xnor': XnorBasicBlock}
+
+
+class QResNet(nn.Module):
+    """Stem (layer0) + three or four stages of basic blocks + average pool and linear classifier.
+
+    ``layer0`` keys: ``n_in_channels`` (width of stage 1), ``kernel_size``, ``stride``,
+    ``padding``, ``bias`` and ``maxpool`` (``{'type': 'identity'}`` or
+    ``{'type': 'maxpool2d', 'kernel_size', 'stride', 'padding'}``).  ``layer1`` .. ``layer4``
+    are keyword dictionaries for the block class (``x_quant``, ``w_quant``, ``clamp`` and, for
+    xnor blocks, ``double_shortcut``); ``layer4`` may be ``None``.
+    """
+
+    def __init__(self, loss_fn: Callable[..., torch.Tensor], block: str, layer0: dict, layer1: dict,
+                 layer2: dict, layer3: dict, layer4: Optional[dict], nonlins: List[str],
+                 num_blocks: List[int], output_classes: int, moving_average_mode: str = 'off',
+                 moving_average_momentum: float = 0.99) -> None:
+        super().__init__()
+        setattr(self, 'loss_fn', loss_fn)
+        if block not in _BLOCKS:
+            raise ValueError(f'Block {block} is not supported.')
+        width = layer0['n_in_channels']
+        self.conv1 = nn.Conv2d(3, width, kernel_size=layer0['kernel_size'], stride=layer0['stride'],
+                               padding=layer0['padding'], bias=layer0['bias'])
+        pool = layer0['maxpool']
+        if pool['type'] == 'identity':
+            self.maxpool = nn.Identity()
+        elif pool['type'] == 'maxpool2d':
+            self.maxpool = nn.MaxPool2d(kernel_size=pool['kernel_size'], stride=pool['stride'],
+                                        padding=pool['padding'])
+        else:
+            raise ValueError(f"maxpool type {pool['type']} is not supported.")
+        self.bn1 = nn.BatchNorm2d(width)
+        self.blocks = nn.ModuleList([nn.Sequential(self.conv1, self.bn1, nn.ReLU(inplace=True), self.maxpool)])
+
+        planes = width
+        stages = [(layer1, width, num_blocks[0], 1), (layer2, 2 * width, num_blocks[1], 2),
+                  (layer3, 4 * width, num_blocks[2], 2)]
+        if layer4 is not None:
+            stages.append((layer4, 8 * width, num_blocks[3], 2))
+        for config, out_planes, count, stride in stages:
+            planes = self._make_layer(_BLOCKS[block], config, planes, out_planes, count, nonlins, stride,
+                                      moving_average_mode, moving_average_momentum)
+        self.linear_classifier = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(),
+                                               nn.Linear(planes, output_classes))
+
+    def _make_layer(self, block, layer_config: dict, in_planes: int, out_planes: int, num_blocks: int,
+                    nonlins: List[str], stride: int, moving_average_mode: str = 'off',
+                    moving_average_momentum: float = 0.99) -> int:
+        """Append ``num_blocks`` blocks (the first one strided); returns the stage's width."""
+        for i in range(num_blocks):
+            self.blocks.append(block(in_planes, out_planes, nonlins=nonlins, stride=stride if i == 0 else 1,
+                                     moving_average_mode=moving_average_mode,
+                                     moving_average_momentum=moving_average_momentum, **layer_config))
+            in_planes = out_planes
+        return in_planes
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        for stage in self.blocks:
+            x = stage(x)
+        return self.linear_classifier(x)
