@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of ResNet-18 (ImageNet, ls-1 weights / ls-2 activations) eval forward.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE); each rank holds a full replica,
+takes its own 256 synthetic 3x224x224 images per step (weak scaling) and the ranks all-gather
+their logits over RCCL every step.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'ml-quant_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def _layer(xq, alpha):
+    return {'x_quant': xq, 'w_quant': 'ls-1', 'clamp': {'kind': 'symmetric', 'alpha': alpha}, 'double_shortcut': True}
+
+
+def imagenet_arch(x_quant='ls-2', alpha=3):
+    """arch_config of examples/imagenet/imagenet_ls1_weight_ls2_activation_kd.yaml (model section)."""
+    return {
+        'moving_average_mode': 'off', 'moving_average_momentum': 0.99, 'block': 'xnor',
+        'layer0': {'n_in_channels': 64, 'kernel_size': 7, 'stride': 2, 'padding': 3, 'bias': False,
+                   'maxpool': {'type': 'maxpool2d', 'kernel_size': 3, 'stride': 2, 'padding': 1}},
+        'layer1': _layer(x_quant, alpha), 'layer2': _layer(x_quant, alpha),
+        'layer3': _layer(x_quant, alpha), 'layer4': _layer(x_quant, alpha),
+        'nonlins': ['relu', 'relu'], 'num_blocks': [2, 2, 2, 2], 'output_classes': 1000}
+
+
+def build_model(arch, device):
+    """Default nn init under manual_seed(0); weight scales as one train-mode forward would cache them
+    (u_o = mean|W_o|, weight_quantization.py:29-31); BatchNorm at its initial running statistics."""
+    from quant.binary.binary_conv import QuantConv2d
+    from quant.models.resnet import QResNet
+    torch.manual_seed(0)
+    model = QResNet(loss_fn=torch.nn.functional.cross_entropy, **arch)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, QuantConv2d) and m.w_quant == 'ls-1':
+                m.w_approximate.v1.copy_(m.weight.abs().mean(dim=(1, 2, 3)))
+    return model.eval().to(device)
+
+
+def cpu_baseline(arch, model, sample):
+    """The oracle's whole-network forward (same algorithmic structure as the reference: sort + cumsum +
+    mask + [N,K,M] cost + fp32 conv) timed on this box's host cores on a bounded sample."""
+    from oracle import ref_models
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(sample, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        ref_models.resnet_forward(sd, arch, x[:2], chunk=16)           # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        ref_models.resnet_forward(sd, arch, x, chunk=16)
+        dt = time.perf_counter() - t0
+    return {'value': sample / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{sample} images of the same workload, one forward ({dt:.1f} s), '
+                      f'host cpu_count={os.cpu_count()}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
+    ap.add_argument('--cpu-sample', type=int, default=48, help='images for the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+
+    from quant import _hip
+    arch = imagenet_arch()
+    model = build_model(arch, device)
+    g = torch.Generator(device='cpu').manual_seed(rank)
+    x = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)       # resident in HBM before timing
+    gathered = torch.empty((world * args.batch, 1000), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            logits = model(x)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, logits)
+        return logits
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_roofline:
+        _hip.enable_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec ResNet-18 LS-1w/LS-2a 224x224 eval forward',
+            'value': world * args.batch * args.steps / elapsed, 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u64 popcount + f32', 'data': 'synthetic',
+            'config': {'workload': 'ResNet-18 ImageNet ls-1 weight / ls-2 activation (configs[2]), '
+                                   f'synthetic 3x224x224, batch {args.batch} per GPU, random-init weights',
+                       'global_batch': world * args.batch, 'parallelism': f'dp{world} (batch-sharded replicas, '
+                                                                          'RCCL all-gather of logits)'},
+        }
+        if not args.no_roofline:
+            stats = _hip.drain_timing()
+            name = max(stats, key=lambda k: stats[k][1])
+            launches, ms, nbytes = stats[name]
+            achieved = nbytes / (ms * 1e-3) / 1e9
+            out['roofline'] = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                               'frac': achieved / 8000.0, 'traffic': None, 'launches': launches,
+                               'avg_launch_us': 1e3 * ms / launches,
+                               'kernels': {k: {'launches': v[0], 'ms_per_step': v[1] / args.steps,
+                                               'algorithmic_GBps': v[2] / (v[1] * 1e-3) / 1e9}
+                                           for k, v in stats.items()}}
+        if args.cpu_sample > 0 and world == 1:
+            out['cpu_baseline'] = cpu_baseline(arch, model, args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -25,6 +25,12 @@
 #include "lsq_common.h"
 
 namespace lsq {
+#ifdef LSQ_PHASE_CLOCKS
+__device__ long long g_phase_clocks[32];
+#define LSQ_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)clock64(); } while (0)
+#else
+#define LSQ_MARK(i) do {} while (0)
+#endif
 namespace {
 
 constexpr int kThreads = 1024;
@@ -32,9 +38,12 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int L1_SHIFT = 19, L1_BINS = 4096;   // key bits [30:19]
 constexpr int L2_SHIFT = 9, L2_BINS = 1024;    // key bits [18:9]
 constexpr int L3_BINS = 512;                   // key bits [8:0]
-constexpr int kSlots1 = 64;                    // level-1 bins refined per round
+constexpr int kSlotCap = 256;                  // flagged level-1 bins held as slot records
+constexpr int kSubSlots = 126;                 // slots gathered per sub-round (role table bytes)
 constexpr int kSeg3 = 8;                       // level-2 bins refined per level-3 pass
-constexpr int kListCap = 14336;                // gathered keys held in LDS
+constexpr int kListCap = 14336;                // gathered keys held in LDS (own region)
+constexpr int kListExt = kListCap + 2 * L1_BINS;   // ... plus the retired level-1 histogram
+constexpr int kWaveSub = 256, kWaveShift = 11; // wave-level refinement: key bits [18:11]
 constexpr unsigned kNoKey = 0xFFFFFFFFu;
 constexpr unsigned long long kOne = 1ull << 42;          // count field of a histogram word
 constexpr unsigned long long kLowMask = kOne - 1;
@@ -51,7 +60,10 @@ __device__ __forceinline__ bool better(const Best& a, const Best& b) {
 }
 
 struct Slot1 {
-  unsigned bin, next_bin, cnt, r0;
+  unsigned short bin, next_bin;   // next_bin = 0xFFFF: none
+  unsigned cnt, r0, succ;         // succ: smallest key above the bin (kNoKey until known)
+  unsigned base;                  // first key of the slot's segment in the LDS list
+  unsigned pad;
   double p0, sum;
 };
 
@@ -60,15 +72,27 @@ struct Seg3 {
   double p0;
 };
 
-struct SolverLds {
-  unsigned long long hist1[L1_BINS];
+struct BlockHists {
   unsigned long long hist2[L2_BINS];
   unsigned hist3[kSeg3][L3_BINS];
+};
+
+struct SolverLds {
+  // `list` and `hist1` are contiguous on purpose: once the level-1 histogram has been read into
+  // registers its 32 KB extend the gathered-key list to kListExt keys.
   unsigned list[kListCap];
+  unsigned long long hist1[L1_BINS];
+  union {
+    BlockHists blk;                                    // block-level (slow) refinement
+    unsigned long long whist[kWaves][kWaveSub];        // wave-level (fast) refinement
+  } u;
+  unsigned wkeys[kWaves][kWave];
   unsigned short nzlist[L1_BINS];
-  unsigned char role[L1_BINS];
-  Slot1 slot[kSlots1];
-  unsigned succ1[kSlots1];
+  unsigned short role[L1_BINS];                        // low byte: 1 + gather slot; high byte: 1 + successor slot
+  Slot1 slot[kSlotCap];
+  unsigned fill[kSubSlots];
+  unsigned short sub_begin[kSlotCap + 2];
+  unsigned short slow[kSubSlots];
   Seg3 seg[kSeg3];
   unsigned succ3[kSeg3];
   // block-scan scratch
@@ -76,7 +100,7 @@ struct SolverLds {
   double ws[kWaves];
   Best wbest[kWaves];
   // scalars
-  unsigned list_n, n_flag, n_cand, round_cnt;
+  unsigned n_sub, n_cand, n_slow, blk_succ;
   unsigned minkey;
   double total;
   float sv[LSQ_MAX_PLANES];
@@ -114,7 +138,8 @@ __device__ __forceinline__ double bin_sum_exact(unsigned hi_key, unsigned cnt, u
     sc = e - 150;
   }
   const long long integer = (long long)cnt * mant + (long long)lowsum;
-  return ldexp((double)integer, sc);
+  // integer < 2^47 is exact in fp64; multiply by the exact power of two 2^sc (sc >= -149)
+  return (double)integer * __longlong_as_double((long long)(sc + 1023) << 52);
 }
 
 struct MPair {
@@ -303,16 +328,36 @@ __device__ __forceinline__ void chain_eval(const Chain& ch, float xv, bool& bit,
   }
 }
 
-template <int VEC, bool HIST, int QM, class L>
-__device__ void pack_pass(const Args& a, const float* __restrict__ xrow, unsigned long long* __restrict__ prow,
-                          const Chain& ch, double& sum_out, unsigned& minkey_out, L* lds) {
+// Which of VEC consecutive elements (flat index = base, base+1, ...) belong to the sub-sample
+// flat % skip == 0 (optimal.py:134)?  `rem` = base % skip.  For the reference's skip = 3 the answer is
+// a select, not a per-element modulo + branch: exactly one of the first three elements is a hit.
+template <int VEC, class F>
+__device__ __forceinline__ void emit_subsample(const float (&x)[VEC], unsigned rem, unsigned skip, F emit) {
+  if (skip == 3u) {
+    if constexpr (VEC == 4) {
+      emit(rem == 0u ? x[0] : (rem == 1u ? x[2 % VEC] : x[1 % VEC]));
+      if (rem == 0u) emit(x[3 % VEC]);
+    } else if constexpr (VEC == 2) {
+      if (rem != 1u) emit(rem == 0u ? x[0] : x[1 % VEC]);
+    } else {
+      if (rem == 0u) emit(x[0]);
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v)
+      if (mod_small(rem + v, skip) == 0u) emit(x[v]);
+  }
+}
+
+// The lane = pixel(s), loop over 64 channels sweep shared by the pack passes and the gather pass.
+// body(cc, x[VEC], rem) is called for every channel of the item with the clamped values.
+template <int VEC, bool NEED_REM, class Begin, class Body, class End>
+__device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict__ xrow, Begin begin, Body body, End end) {
   const int HW = a.H * a.W;
   const int PV = (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   const unsigned skip = (unsigned)a.skip;
   const unsigned step = (unsigned)(HW % a.skip);
-  double acc = 0.0;
-  unsigned mk = kNoKey;
   for (int item = threadIdx.x; item < items; item += kThreads) {
     const int j = item / PV;
     const int p = (item - j * PV) * VEC;
@@ -321,51 +366,89 @@ __device__ void pack_pass(const Args& a, const float* __restrict__ xrow, unsigne
     const int c0 = grp * a.cg + jj * 64;
     const int nch = min(64, a.cg - jj * 64);
     const float* src = xrow + (long long)c0 * HW + p;
-    unsigned long long word[VEC];
+    unsigned rem = NEED_REM ? (unsigned)(((long long)c0 * HW + p) % (long long)skip) : 0u;
+    begin();
+    // U independent loads are issued before any of them is consumed: LDS atomics in the body
+    // would otherwise pin every load to its use and leave one request in flight per lane.
+    constexpr int U = 32 / VEC;
+    for (int cb = 0; cb < nch; cb += U) {
+      float vals[U][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) word[v] = 0ull;
-    unsigned rem = HIST ? (unsigned)(((long long)c0 * HW + p) % (long long)skip) : 0u;
-#pragma unroll 8
-    for (int cc = 0; cc < nch; ++cc) {
-      float vals[VEC];
-      if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(src + (long long)cc * HW);
-        vals[0] = t.x; vals[1 % VEC] = t.y; vals[2 % VEC] = t.z; vals[3 % VEC] = t.w;
-      } else if (VEC == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(src + (long long)cc * HW);
-        vals[0] = t.x; vals[1 % VEC] = t.y;
-      } else {
-        vals[0] = src[(long long)cc * HW];
+      for (int u = 0; u < U; ++u) {
+        const int cc = min(cb + u, nch - 1);
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src + (long long)cc * HW);
+          vals[u][0] = t.x; vals[u][1 % VEC] = t.y; vals[u][2 % VEC] = t.z; vals[u][3 % VEC] = t.w;
+        } else if (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(src + (long long)cc * HW);
+          vals[u][0] = t.x; vals[u][1 % VEC] = t.y;
+        } else {
+          vals[u][0] = src[(long long)cc * HW];
+        }
       }
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const float xv = clamp_sym(vals[v], a.alpha);
-        bool bit;
-        float ar;
-        chain_eval<QM>(ch, xv, bit, ar);
-        word[v] |= (unsigned long long)bit << cc;
-        acc += (double)ar;
-        if constexpr (HIST) {
-          if (mod_small(rem + v, skip) == 0u) {
-            const unsigned key = abs_key(xv);
-            atomicAdd(&lds->hist1[key >> L1_SHIFT], kOne | (unsigned long long)(key & ((1u << L1_SHIFT) - 1u)));
-            mk = min(mk, key);
+      for (int u = 0; u < U; ++u) {
+        const int cc = cb + u;
+        if (cc < nch) {
+          float x[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(vals[u][v], a.alpha);
+          body(cc, x, rem);
+          if constexpr (NEED_REM) {
+            rem += step;
+            if (rem >= skip) rem -= skip;
           }
         }
       }
-      if constexpr (HIST) {
-        rem += step;
-        if (rem >= skip) rem -= skip;
-      }
     }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const int pix = p + v;
-      const int h = pix / a.W;
-      const int w = pix - h * a.W;
-      prow[((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w] = word[v];
-    }
+    end(j, p);
   }
+}
+
+template <int VEC, bool HIST, int QM, class L>
+__device__ void pack_pass(const Args& a, const float* __restrict__ xrow, unsigned long long* __restrict__ prow,
+                          const Chain& ch, double& sum_out, unsigned& minkey_out, L* lds) {
+  const unsigned skip = (unsigned)a.skip;
+  double acc = 0.0;
+  unsigned mk = kNoKey;
+  unsigned long long word[VEC];
+  float facc[VEC];            // fp32 over one 64-channel column, folded into fp64 per item
+  sweep_row<VEC, HIST>(
+      a, xrow,
+      [&]() {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          word[v] = 0ull;
+          facc[v] = 0.f;
+        }
+      },
+      [&](int cc, const float (&x)[VEC], unsigned rem) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          bool bit;
+          float ar;
+          chain_eval<QM>(ch, x[v], bit, ar);
+          word[v] |= (unsigned long long)bit << cc;
+          facc[v] += ar;
+        }
+        if constexpr (HIST) {
+          emit_subsample<VEC>(x, rem, skip, [&](float xs) {
+            const unsigned key = abs_key(xs);
+            atomicAdd(&lds->hist1[key >> L1_SHIFT], kOne | (unsigned long long)(key & ((1u << L1_SHIFT) - 1u)));
+            mk = min(mk, key);
+          });
+        }
+      },
+      [&](int j, int p) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          acc += (double)facc[v];
+          const int pix = p + v;
+          const int h = pix / a.W;
+          const int w = pix - h * a.W;
+          prow[((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w] = word[v];
+        }
+      });
   sum_out = acc;
   minkey_out = mk;
 }
@@ -399,13 +482,25 @@ __device__ void flat_pass(const Args& a, const float* __restrict__ xrow, const C
 // sub-sampled keys of the row (optimal.py:134), straight from memory (L2 / Infinity Cache)
 template <class F>
 __device__ __forceinline__ void for_each_row_key(const Args& a, const float* __restrict__ xrow, unsigned n, F f) {
-  for (unsigned j = threadIdx.x; j < n; j += kThreads)
-    f(abs_key(clamp_sym(xrow[(long long)j * a.skip], a.alpha)));
+  constexpr int U = 8;
+  const long long skip = a.skip;
+  for (unsigned j0 = threadIdx.x; j0 < n; j0 += kThreads * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = min(j0 + (unsigned)u * kThreads, n - 1u);
+      v[u] = xrow[(long long)j * skip];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j0 + (unsigned)u * kThreads < n) f(abs_key(clamp_sym(v[u], a.alpha)));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // The solve.  On entry hist1 holds the level-1 histogram of the n sub-sampled keys.
-__device__ float solve_v1(const Args& a, const float* __restrict__ xrow, unsigned n, unsigned minkey,
+template <int VEC>
+__device__ __noinline__ float solve_v1(const Args& a, const float* __restrict__ xrow, unsigned n, unsigned minkey,
                           SolverLds* lds, unsigned* n_candidates) {
   const bool ternary = a.ternary != 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -413,275 +508,521 @@ __device__ float solve_v1(const Args& a, const float* __restrict__ xrow, unsigne
   best.cost = INFINITY;
   best.order = kNoKey;
   best.value = 0.f;
-  if (tid == 0) {
-    lds->n_cand = 0;
-  }
-
-  // ---- level 1: each thread owns 4 consecutive bins
-  unsigned cnt[4], r0[4], nxt[4];
-  double sum[4], p0[4];
-  bool flag[4];
-  unsigned my_nz = 0, my_cnt = 0;
-  double my_sum = 0.0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned b = 4u * tid + u;
-    const unsigned long long h = lds->hist1[b];
-    cnt[u] = (unsigned)(h >> 42);
-    sum[u] = cnt[u] ? bin_sum_exact(b << L1_SHIFT, cnt[u], h & kLowMask) : 0.0;
-    my_nz += cnt[u] ? 1u : 0u;
-    my_cnt += cnt[u];
-    my_sum += sum[u];
-  }
-  unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
-  double esum = my_sum, total;
-  block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
-  {
-    unsigned z = enz, c = ecnt;
-    double s = esum;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      r0[u] = c;
-      p0[u] = s;
-      if (cnt[u]) lds->nzlist[z++] = (unsigned short)(4u * tid + u);
-      c += cnt[u];
-      s += sum[u];
+  if (tid == 0) lds->n_cand = 0;
+  unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
+  // every sub-sampled key of the row: coalesced full-row sweep for activations (the strided
+  // 4-byte gather was 2.5x slower than re-reading the whole row), strided for dense flat rows
+  auto sweep_keys = [&](auto&& f) {
+    if (a.flat) {
+      for_each_row_key(a, xrow, n, f);
+    } else {
+      const unsigned skip = (unsigned)a.skip;
+      sweep_row<VEC, true>(
+          a, xrow, []() {},
+          [&](int, const float (&x)[VEC], unsigned rem) {
+            emit_subsample<VEC>(x, rem, skip, [&](float xs) { f(abs_key(xs)); });
+          },
+          [](int, int) {});
     }
-  }
-  if (tid == 0) lds->total = total;
-  __syncthreads();
-  unsigned my_flags = 0;
-  {
-    unsigned z = enz;
+  };
+  LSQ_MARK(2);
+
+  // ---- level 1: scan the 4096-bin histogram (4 bins per thread), flag bins that may hold a
+  //      candidate, and write a slot record for the flagged bins with ordinal in [round0, round0+cap)
+  double total = 0.0;
+  auto l1_scan = [&](unsigned round0) -> unsigned {
+    unsigned cnt[4];
+    double sum[4];
+    unsigned my_nz = 0, my_cnt = 0;
+    double my_sum = 0.0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      flag[u] = false;
-      nxt[u] = kNoKey;
-      if (cnt[u]) {
-        const unsigned b = 4u * tid + u;
-        const double vlo = (double)key_value(b << L1_SHIFT);
-        const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
-        double next_hi = vhi;
-        if (z + 1 < tnz) {
-          nxt[u] = lds->nzlist[z + 1];
-          next_hi = (double)key_value((nxt[u] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+      const unsigned b = 4u * tid + u;
+      const unsigned long long h = lds->hist1[b];
+      cnt[u] = (unsigned)(h >> 42);
+      sum[u] = cnt[u] ? bin_sum_exact(b << L1_SHIFT, cnt[u], h & kLowMask) : 0.0;
+      my_nz += cnt[u] ? 1u : 0u;
+      my_cnt += cnt[u];
+      my_sum += sum[u];
+    }
+    unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
+    double esum = my_sum;
+    block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
+    {
+      unsigned z = enz;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (cnt[u]) lds->nzlist[z++] = (unsigned short)(4u * tid + u);
+    }
+    __syncthreads();
+    unsigned my_flags = 0;
+    bool flag[4];
+    unsigned short nxt[4];
+    {
+      unsigned z = enz, c = ecnt;
+      double s = esum;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        flag[u] = false;
+        nxt[u] = 0xFFFFu;
+        if (cnt[u]) {
+          const unsigned b = 4u * tid + u;
+          const double vlo = (double)key_value(b << L1_SHIFT);
+          const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+          double next_hi = vhi;
+          if (z + 1 < tnz) {
+            nxt[u] = lds->nzlist[z + 1];
+            next_hi = (double)key_value(((unsigned)nxt[u] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+          }
+          flag[u] = n >= 3u && may_hold_candidate(c, cnt[u], s, sum[u], vlo, vhi, next_hi, n, total, ternary);
+          my_flags += flag[u] ? 1u : 0u;
+          ++z;
         }
-        flag[u] = n >= 3u && may_hold_candidate(r0[u], cnt[u], p0[u], sum[u], vlo, vhi, next_hi, n, total, ternary);
-        my_flags += flag[u] ? 1u : 0u;
-        ++z;
+        c += cnt[u];
+        s += sum[u];
       }
     }
-  }
-  unsigned eflag = my_flags, dummy = 0, tflag, tdummy;
-  double dzero = 0.0, tdz;
-  block_excl_scan(eflag, dummy, dzero, tflag, tdummy, tdz, lds);
-
-  // ---- rounds over flagged level-1 bins
-  for (unsigned round0 = 0; round0 < tflag; round0 += kSlots1) {
-    const unsigned nslot = min((unsigned)kSlots1, tflag - round0);
-    __syncthreads();
-    for (int i = tid; i < L1_BINS; i += kThreads) lds->role[i] = 0;
-    if (tid == 0) {
-      lds->list_n = 0;
-      lds->round_cnt = 0;
-    }
-    if (tid < kSlots1) lds->succ1[tid] = kNoKey;
-    __syncthreads();
+    unsigned eflag = my_flags, dummy = 0, tflag, tdummy;
+    double dzero = 0.0, tdz;
+    block_excl_scan(eflag, dummy, dzero, tflag, tdummy, tdz, lds);
     {
-      unsigned ord = eflag;
+      unsigned ord = eflag, c = ecnt;
+      double s = esum;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (flag[u]) {
-          if (ord >= round0 && ord < round0 + nslot) {
-            Slot1 s;
-            s.bin = 4u * tid + u;
-            s.next_bin = nxt[u];
-            s.cnt = cnt[u];
-            s.r0 = r0[u];
-            s.p0 = p0[u];
-            s.sum = sum[u];
-            lds->slot[ord - round0] = s;
-            atomicAdd(&lds->round_cnt, cnt[u]);
+          if (ord >= round0 && ord < round0 + (unsigned)kSlotCap) {
+            Slot1 sl;
+            sl.bin = (unsigned short)(4u * tid + u);
+            sl.next_bin = nxt[u];
+            sl.cnt = cnt[u];
+            sl.r0 = c;
+            sl.succ = kNoKey;
+            sl.base = 0;
+            sl.pad = 0;
+            sl.p0 = s;
+            sl.sum = sum[u];
+            lds->slot[ord - round0] = sl;
           }
           ++ord;
         }
+        c += cnt[u];
+        s += sum[u];
       }
     }
     __syncthreads();
-    const bool use_list = lds->round_cnt <= (unsigned)kListCap;
-    if (use_list) {
-      // role: bit 7 = gather this bin; low 7 bits = 1 + slot whose successor lives in this bin
-      if (tid < (int)nslot) {
-        const Slot1 s = lds->slot[tid];
-        atomicOr((unsigned*)&lds->role[s.bin & ~3u], 0x80u << (8 * (s.bin & 3u)));
-        if (s.next_bin != kNoKey)
-          atomicOr((unsigned*)&lds->role[s.next_bin & ~3u], (unsigned)(tid + 1) << (8 * (s.next_bin & 3u)));
-      }
-      __syncthreads();
-      for_each_row_key(a, xrow, n, [&](unsigned key) {
-        const unsigned r = lds->role[key >> L1_SHIFT];
-        if (r & 0x80u) lds->list[atomicAdd(&lds->list_n, 1u)] = key;
-        const unsigned sd = r & 0x7Fu;
-        if (sd && key < lds->succ1[sd - 1]) atomicMin(&lds->succ1[sd - 1], key);
-      });
-      __syncthreads();
+    return tflag;
+  };
+
+  // ---- block-level refinement of one slot: levels 2 (10 bits) and 3 (9 bits) as histograms.
+  //      Fully general (any count, any ties) but costs ~15 workgroup barriers, so it only serves
+  //      what the wave-level path gives up on.  from_row: histogram straight from the row (bins too
+  //      large for the LDS list); otherwise from the slot's segment of the list.
+  auto resolve_slot_block = [&](unsigned si, bool from_row) {
+    const Slot1 s1 = lds->slot[si];
+    const unsigned s1_bin = s1.bin;
+    const unsigned s1_next = s1.next_bin == 0xFFFFu ? kNoKey : (unsigned)s1.next_bin;
+    __syncthreads();
+    for (int i = tid; i < L2_BINS; i += kThreads) lds->u.blk.hist2[i] = 0ull;
+    if (tid == 0) lds->blk_succ = s1.succ;
+    __syncthreads();
+    auto l2 = [&](unsigned key) {
+      const unsigned b = key >> L1_SHIFT;
+      if (b == s1_bin)
+        atomicAdd(&lds->u.blk.hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
+                  kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
+      else if (from_row && b == s1_next && key < lds->blk_succ)
+        atomicMin(&lds->blk_succ, key);
+    };
+    if (from_row) {
+      for_each_row_key(a, xrow, n, l2);
+    } else {
+      for (unsigned i = tid; i < s1.cnt; i += kThreads) l2(list[s1.base + i]);
     }
-    const unsigned list_n = lds->list_n;
+    __syncthreads();
+    const unsigned succ_b = lds->blk_succ;
+    // thread t owns sub-bin t
+    const unsigned long long h2 = lds->u.blk.hist2[tid];
+    const unsigned c2 = (unsigned)(h2 >> 42);
+    const unsigned hi_key2 = (s1_bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
+    const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
+    unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
+    double es2 = s2, ts2;
+    block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
+    if (c2) lds->nzlist[enz2] = (unsigned short)tid;   // level-1 use of nzlist is over
+    __syncthreads();
+    const unsigned r02 = s1.r0 + ec2;
+    const double p02 = s1.p0 + es2;
+    unsigned next_sub = kNoKey;
+    bool f2 = false;
+    if (c2) {
+      const double vlo = (double)key_value(hi_key2);
+      const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
+      double next_hi = vhi;
+      if (enz2 + 1 < tnz2) {
+        next_sub = lds->nzlist[enz2 + 1];
+        next_hi = (double)key_value((s1_bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
+      } else if (succ_b != kNoKey) {
+        next_hi = (double)key_value(succ_b);
+      }
+      f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, total, ternary);
+    }
+    unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
+    double dz2 = 0.0, tdz2;
+    block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
 
-    for (unsigned si = 0; si < nslot; ++si) {
-      const Slot1 s1 = lds->slot[si];
-      // ---- level 2 histogram of bin s1.bin
+    // ---- level 3 in batches of kSeg3 flagged sub-bins
+    for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
+      const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
       __syncthreads();
-      for (int i = tid; i < L2_BINS; i += kThreads) lds->hist2[i] = 0ull;
+      if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
+        Seg3 g;
+        g.pref = (s1_bin << 10) | (unsigned)tid;
+        g.next_pref = next_sub != kNoKey ? ((s1_bin << 10) | next_sub) : kNoKey;
+        g.cnt = c2;
+        g.r0 = r02;
+        g.p0 = p02;
+        lds->seg[ef2 - b3] = g;
+        lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
+      }
+      for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->u.blk.hist3[0][0])[i] = 0u;
       __syncthreads();
-      auto l2 = [&](unsigned key) {
-        const unsigned b = key >> L1_SHIFT;
-        if (b == s1.bin)
-          atomicAdd(&lds->hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
-                    kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
-        else if (!use_list && b == s1.next_bin && key < lds->succ1[si])
-          atomicMin(&lds->succ1[si], key);
+      auto l3 = [&](unsigned key) {
+        const unsigned p = key >> L2_SHIFT;
+        for (unsigned j = 0; j < nseg; ++j) {
+          if (p == lds->seg[j].pref)
+            atomicAdd(&lds->u.blk.hist3[j][key & (L3_BINS - 1)], 1u);
+          else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
+            atomicMin(&lds->succ3[j], key);
+        }
       };
-      if (use_list) {
-        for (unsigned i = tid; i < list_n; i += kThreads) l2(lds->list[i]);
+      if (from_row) {
+        for_each_row_key(a, xrow, n, l3);
       } else {
-        for_each_row_key(a, xrow, n, l2);
+        for (unsigned i = tid; i < s1.cnt; i += kThreads) l3(list[s1.base + i]);
       }
       __syncthreads();
-      const unsigned succ_b = lds->succ1[si];
-      // thread t owns sub-bin t
-      const unsigned long long h2 = lds->hist2[tid];
-      const unsigned c2 = (unsigned)(h2 >> 42);
-      const unsigned hi_key2 = (s1.bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
-      const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
-      unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
-      double es2 = s2, ts2;
-      block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
-      if (c2) lds->nzlist[enz2] = (unsigned short)tid;   // level-1 use of nzlist is over
-      __syncthreads();
-      const unsigned r02 = s1.r0 + ec2;
-      const double p02 = s1.p0 + es2;
-      unsigned next_sub = kNoKey;
-      bool f2 = false;
-      if (c2) {
-        const double vlo = (double)key_value(hi_key2);
-        const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
-        double next_hi = vhi;
-        if (enz2 + 1 < tnz2) {
-          next_sub = lds->nzlist[enz2 + 1];
-          next_hi = (double)key_value((s1.bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
-        } else if (succ_b != kNoKey) {
-          next_hi = (double)key_value(succ_b);
+      // wave j resolves segment j: lane owns 8 consecutive keys
+      if ((unsigned)wid < nseg) {
+        const Seg3 g = lds->seg[wid];
+        const unsigned succ_s = lds->succ3[wid];
+        unsigned kc[8];
+        unsigned lane_cnt = 0;
+        double lane_sum = 0.0;
+        unsigned first_key = kNoKey;
+#pragma unroll
+        for (int u = 7; u >= 0; --u) {
+          kc[u] = lds->u.blk.hist3[wid][lane * 8 + u];
+          if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
         }
-        f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, lds->total, ternary);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          lane_cnt += kc[u];
+          lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u));
+        }
+        const unsigned ic = wave_incl_scan(lane_cnt);
+        const double is = wave_incl_scan(lane_sum);
+        unsigned after = kNoKey;          // next non-empty key in a higher lane
+        {
+          unsigned sfx = first_key;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_down(sfx, d);
+            if (lane + d < 64) sfx = min(sfx, o);
+          }
+          const unsigned up1 = __shfl_down(sfx, 1);
+          after = lane < 63 ? up1 : kNoKey;
+        }
+        unsigned run_r0 = g.r0 + (ic - lane_cnt);
+        double run_p0 = g.p0 + (is - lane_sum);
+        unsigned nextk[8];
+        unsigned cur = after != kNoKey ? after : succ_s;
+#pragma unroll
+        for (int u = 7; u >= 0; --u) {
+          nextk[u] = cur;
+          if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (kc[u]) {
+            const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+            const double v = (double)key_value(key);
+            const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
+            if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, total, ternary)) {
+              Best c;
+              c.cost = cost_of(v, run_r0, run_p0, kc[u], n, total, ternary);
+              c.order = run_r0;
+              c.value = key_value(key);
+              if (better(c, best)) best = c;
+              atomicAdd(&lds->n_cand, 1u);
+            }
+            run_r0 += kc[u];
+            run_p0 += (double)kc[u] * v;
+          }
+        }
       }
-      unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
-      double dz2 = 0.0, tdz2;
-      block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
+    }
+  };
 
-      // ---- level 3 in batches of kSeg3 flagged sub-bins
-      for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
-        const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
-        __syncthreads();
-        if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
-          Seg3 g;
-          g.pref = (s1.bin << 10) | (unsigned)tid;
-          g.next_pref = next_sub != kNoKey ? ((s1.bin << 10) | next_sub) : kNoKey;
-          g.cnt = c2;
-          g.r0 = r02;
-          g.p0 = p02;
-          lds->seg[ef2 - b3] = g;
-          lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
-        }
-        for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->hist3[0][0])[i] = 0u;
-        __syncthreads();
-        auto l3 = [&](unsigned key) {
-          const unsigned p = key >> L2_SHIFT;
-          for (unsigned j = 0; j < nseg; ++j) {
-            if (p == lds->seg[j].pref)
-              atomicAdd(&lds->hist3[j][key & (L3_BINS - 1)], 1u);
-            else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
-              atomicMin(&lds->succ3[j], key);
-          }
-        };
-        if (use_list) {
-          for (unsigned i = tid; i < list_n; i += kThreads) l3(lds->list[i]);
-        } else {
-          for_each_row_key(a, xrow, n, l3);
-        }
-        __syncthreads();
-        // wave j resolves segment j: lane owns 8 consecutive keys
-        if ((unsigned)wid < nseg) {
-          const Seg3 g = lds->seg[wid];
-          const unsigned succ_s = lds->succ3[wid];
-          unsigned kc[8];
-          unsigned lane_cnt = 0;
-          double lane_sum = 0.0;
-          unsigned first_key = kNoKey;
+  // ---- wave-level refinement of one slot whose keys sit in list[base, base+cnt): 256-way
+  //      histogram of key bits [18:11] private to the wave, then every flagged sub-bin is either
+  //      a run of equal keys (resolved analytically) or has <= 64 keys (ranked by brute force with
+  //      shuffles).  No workgroup barrier: the 16 waves resolve 16 slots concurrently.  Returns
+  //      false to hand the slot to resolve_slot_block.
+  auto resolve_slot_wave = [&](unsigned si) -> bool {
+    const Slot1 s1 = lds->slot[si];
+    const unsigned s1_bin = s1.bin;
+    const unsigned succ_b = s1.succ;
+    const unsigned* const seg = list + s1.base;
+    const unsigned seg_n = s1.cnt;
+    unsigned long long* const h = lds->u.whist[wid];
+    unsigned* const wk = lds->wkeys[wid];
 #pragma unroll
-          for (int u = 7; u >= 0; --u) {
-            kc[u] = lds->hist3[wid][lane * 8 + u];
-            if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
-          }
+    for (int u = 0; u < 4; ++u) h[lane * 4 + u] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (unsigned i = lane; i < seg_n; i += kWave) {
+      const unsigned key = seg[i];
+      atomicAdd(&h[(key >> kWaveShift) & (kWaveSub - 1)], kOne | (unsigned long long)(key & ((1u << kWaveShift) - 1u)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned c[4], lane_cnt = 0, first_sub = kNoKey;
+    double sm[4], lane_sum = 0.0;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            lane_cnt += kc[u];
-            lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u));
-          }
-          const unsigned ic = wave_incl_scan(lane_cnt);
-          const double is = wave_incl_scan(lane_sum);
-          // next non-empty key after this lane's keys: suffix-min over higher lanes
-          unsigned after = kNoKey;
-          {
-            unsigned sm = first_key;   // suffix min including own lane
+    for (int u = 3; u >= 0; --u) {
+      const unsigned long long hv = h[lane * 4 + u];
+      c[u] = (unsigned)(hv >> 42);
+      const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
+      sm[u] = c[u] ? bin_sum_exact(hi_key, c[u], hv & kLowMask) : 0.0;
+      if (c[u]) first_sub = (unsigned)(lane * 4 + u);
+    }
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-              const unsigned o = __shfl_down(sm, d);
-              if (lane + d < 64) sm = min(sm, o);
-            }
-            const unsigned up1 = __shfl_down(sm, 1);
-            after = lane < 63 ? up1 : kNoKey;
-          }
-          unsigned run_r0 = g.r0 + (ic - lane_cnt);
-          double run_p0 = g.p0 + (is - lane_sum);
-          // successor key of each own key
-          unsigned nextk[8];
-          unsigned cur = after != kNoKey ? after : succ_s;
+    for (int u = 0; u < 4; ++u) {
+      lane_cnt += c[u];
+      lane_sum += sm[u];
+    }
+    const unsigned ic = wave_incl_scan(lane_cnt);
+    const double is = wave_incl_scan(lane_sum);
+    unsigned after = kNoKey;                      // first non-empty sub-bin in a higher lane
+    {
+      unsigned sfx = first_sub;
 #pragma unroll
-          for (int u = 7; u >= 0; --u) {
-            nextk[u] = cur;
-            if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
-          }
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_down(sfx, d);
+        if (lane + d < 64) sfx = min(sfx, o);
+      }
+      const unsigned up1 = __shfl_down(sfx, 1);
+      after = lane < 63 ? up1 : kNoKey;
+    }
+    unsigned nsub[4], r0s[4];
+    double p0s[4];
+    bool fl[4];
+    {
+      unsigned cur = after;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (kc[u]) {
-              const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
-              const double v = (double)key_value(key);
-              const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
-              if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, lds->total, ternary)) {
-                Best c;
-                c.cost = cost_of(v, run_r0, run_p0, kc[u], n, lds->total, ternary);
-                c.order = run_r0;
-                c.value = key_value(key);
-                if (better(c, best)) best = c;
-                atomicAdd(&lds->n_cand, 1u);
-              }
-              run_r0 += kc[u];
-              run_p0 += (double)kc[u] * v;
-            }
-          }
+      for (int u = 3; u >= 0; --u) {
+        nsub[u] = cur;
+        if (c[u]) cur = (unsigned)(lane * 4 + u);
+      }
+      unsigned rr = s1.r0 + (ic - lane_cnt);
+      double pp = s1.p0 + (is - lane_sum);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        r0s[u] = rr;
+        p0s[u] = pp;
+        rr += c[u];
+        pp += sm[u];
+        fl[u] = false;
+        if (c[u]) {
+          const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
+          const double vlo = (double)key_value(hi_key);
+          const double vhi = (double)key_value(hi_key | ((1u << kWaveShift) - 1u));
+          double next_hi = vhi;
+          if (nsub[u] != kNoKey)
+            next_hi = (double)key_value((s1_bin << L1_SHIFT) | (nsub[u] << kWaveShift) | ((1u << kWaveShift) - 1u));
+          else if (succ_b != kNoKey)
+            next_hi = (double)key_value(succ_b);
+          fl[u] = may_hold_candidate(r0s[u], c[u], p0s[u], sm[u], vlo, vhi, next_hi, n, total, ternary);
         }
       }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      unsigned long long todo = __ballot(fl[u]);
+      while (todo) {                               // wave-uniform loop over flagged sub-bins
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const unsigned sub = (unsigned)(src * 4 + u);
+        const unsigned cc = __shfl(c[u], src);
+        const unsigned rs = __shfl(r0s[u], src);
+        const double ps = __shfl(p0s[u], src);
+        const unsigned ns = __shfl(nsub[u], src);
+        const unsigned pref = (s1_bin << 8) | sub;
+        const unsigned npref = ns != kNoKey ? ((s1_bin << 8) | ns) : kNoKey;
+        // one sweep of the segment: this sub-bin's keys (first 64) + its min/max + successor key
+        unsigned pos = 0, succ_l = kNoKey, kmin = kNoKey, kmax = 0u;
+        for (unsigned i0 = 0; i0 < seg_n; i0 += kWave) {
+          const unsigned i = i0 + lane;
+          const unsigned key = i < seg_n ? seg[i] : kNoKey;
+          const unsigned pk = key >> kWaveShift;
+          const bool mine = i < seg_n && pk == pref;
+          const unsigned long long mm = __ballot(mine);
+          if (mine) {
+            const unsigned at = pos + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+            if (at < (unsigned)kWave) wk[at] = key;
+            kmin = min(kmin, key);
+            kmax = max(kmax, key);
+          }
+          pos += (unsigned)__popcll(mm);
+          if (i < seg_n && pk == npref) succ_l = min(succ_l, key);
+        }
+        const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : succ_b;
+        const double succ_v = succ_k != kNoKey ? (double)key_value(succ_k) : INFINITY;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (cc > (unsigned)kWave) {
+          kmin = wave_min(kmin);
+          kmax = ~wave_min(~kmax);
+          if (kmin != kmax) {
+            ok = false;                            // many distinct keys in one sub-bin: block path
+            continue;
+          }
+          // a run of cc equal keys (saturated clamp value, exact zeros, constant rows)
+          const double v = (double)key_value(kmin);
+          if (run_has_candidate(v, cc, rs, ps, succ_v, n, total, ternary)) {
+            Best cb;
+            cb.cost = cost_of(v, rs, ps, cc, n, total, ternary);
+            cb.order = rs;
+            cb.value = key_value(kmin);
+            if (better(cb, best)) best = cb;
+            if (lane == 0) atomicAdd(&lds->n_cand, 1u);
+          }
+          continue;
+        }
+        const bool act = (unsigned)lane < cc;
+        const unsigned key = act ? wk[lane] : kNoKey;
+        unsigned rank = 0, below = 0, eq = 0;
+        double bsum = 0.0, psum = 0.0;
+        for (unsigned j = 0; j < cc; ++j) {
+          const unsigned kj = __shfl(key, (int)j);
+          const double vj = (double)key_value(kj);
+          const bool lt = kj < key, e = kj == key;
+          below += lt ? 1u : 0u;
+          eq += e ? 1u : 0u;
+          if (lt) bsum += vj;
+          if (lt || (e && j <= (unsigned)lane)) psum += vj;
+          if (lt || (e && j < (unsigned)lane)) ++rank;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (act) wk[rank] = key;                   // sorted order
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        bool cand = false;
+        if (act) {
+          const unsigned nk = rank + 1u < cc ? wk[rank + 1u] : succ_k;
+          const double v = (double)key_value(key);
+          const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
+          const long long i = (long long)rs + rank;
+          cand = i >= 1 && i <= (long long)n - 2 &&
+                 position_is_candidate(v, nv, (double)(i + 1), ps + psum, (double)n, total, ternary);
+          if (cand) {
+            Best cb;
+            cb.cost = cost_of(v, rs + below, ps + bsum, eq, n, total, ternary);
+            cb.order = rs + below;
+            cb.value = key_value(key);
+            if (better(cb, best)) best = cb;
+          }
+        }
+        const unsigned long long firsts = __ballot(cand && below == rank);
+        if (lane == 0 && firsts) atomicAdd(&lds->n_cand, (unsigned)__popcll(firsts));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+    return ok;
+  };
+
+  unsigned tflag = l1_scan(0);
+  LSQ_MARK(3);
+  if (tflag > (unsigned)kSlotCap) {
+    // pathological rows (hundreds of crossing bins): no LDS list, so hist1 stays intact and the
+    // scan can be repeated for each group of kSlotCap flagged bins
+    for (unsigned round0 = 0; round0 < tflag; round0 += kSlotCap) {
+      if (round0) l1_scan(round0);
+      const unsigned nslot = min((unsigned)kSlotCap, tflag - round0);
+      for (unsigned si = 0; si < nslot; ++si) resolve_slot_block(si, true);
+    }
+  } else if (tflag) {
+    if (tid == 0) {                                 // greedy split by gathered-key capacity
+      unsigned ns = 0, begin = 0, acc = 0;
+      for (unsigned q = 0; q < tflag; ++q) {
+        const unsigned cq = lds->slot[q].cnt;
+        if (q > begin && (acc + cq > (unsigned)kListExt || q - begin >= (unsigned)kSubSlots)) {
+          lds->sub_begin[ns++] = (unsigned short)begin;
+          begin = q;
+          acc = 0;
+        }
+        lds->slot[q].base = acc;
+        acc += cq;
+      }
+      lds->sub_begin[ns++] = (unsigned short)begin;
+      lds->sub_begin[ns] = (unsigned short)tflag;
+      lds->n_sub = ns;
+    }
+    __syncthreads();
+    const unsigned n_sub = lds->n_sub;
+    for (unsigned sr = 0; sr < n_sub; ++sr) {
+      const unsigned sb = lds->sub_begin[sr], se = lds->sub_begin[sr + 1];
+      __syncthreads();
+      if (se - sb == 1u && lds->slot[sb].cnt > (unsigned)kListExt) {
+        resolve_slot_block(sb, true);              // one huge bin: histogram straight from the row
+        continue;
+      }
+      for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->role)[i] = 0u;
+      if (tid < kSubSlots) lds->fill[tid] = 0u;
+      if (tid == 0) lds->n_slow = 0;
+      __syncthreads();
+      if ((unsigned)tid < se - sb) {
+        const Slot1 sl = lds->slot[sb + tid];
+        atomicOr((unsigned*)&lds->role[sl.bin & ~1u], (unsigned)(tid + 1) << (16 * (sl.bin & 1u)));
+        if (sl.next_bin != 0xFFFFu)
+          atomicOr((unsigned*)&lds->role[sl.next_bin & ~1u], (unsigned)(tid + 1) << (8 + 16 * (sl.next_bin & 1u)));
+      }
+      __syncthreads();
+      // gather pass: every key of a flagged bin goes to its slot's segment of the LDS list; keys of
+      // the bin right above a flagged bin update that slot's successor key
+      auto take = [&](unsigned key) {
+        const unsigned r = lds->role[key >> L1_SHIFT];
+        const unsigned gs = r & 0xFFu, ss = r >> 8;
+        if (gs) {
+          const Slot1* sl = &lds->slot[sb + gs - 1u];
+          list[sl->base + atomicAdd(&lds->fill[gs - 1u], 1u)] = key;
+        }
+        if (ss) {
+          unsigned* sp = &lds->slot[sb + ss - 1u].succ;
+          if (key < *sp) atomicMin(sp, key);
+        }
+      };
+      sweep_keys(take);
+      __syncthreads();
+      LSQ_MARK(4);
+      for (unsigned si = sb + (unsigned)wid; si < se; si += kWaves) {
+        if (!resolve_slot_wave(si)) {
+          if (lane == 0) lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)si;
+        }
+      }
+      __syncthreads();
+      LSQ_MARK(5);
+      const unsigned n_slow = lds->n_slow;
+      for (unsigned q = 0; q < n_slow; ++q) resolve_slot_block(lds->slow[q], false);
     }
   }
+  LSQ_MARK(6);
 
   // ---- ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
   if (ternary && n > 0u && tid == 0) {
-    const double mean = lds->total / (double)n;
+    const double mean = total / (double)n;
     if ((double)key_value(minkey) > 0.5 * mean) {
       const float half = (float)((double)((float)mean) / 2.0);
       Best c;
-      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, lds->total, true);
+      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, total, true);
       c.order = n + 1u;
       c.value = half;
       if (better(c, best)) best = c;
@@ -727,6 +1068,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_kernel(Args a) {
   __syncthreads();
 
   Chain ch;
+  LSQ_MARK(0);
   for (int q = 0; q < a.k; ++q) {
     ch.q = q;
 #pragma unroll
@@ -755,6 +1097,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_kernel(Args a) {
         pack_pass<VEC, false, 2>(a, xrow, prow, ch, part, mk, lds);
       }
     }
+    LSQ_MARK(1 + 7 * q);
     const double tot = block_sum(part, lds);
     float vq = (float)(tot / (double)a.row_elems);
     if (SOLVER) {
@@ -767,7 +1110,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_kernel(Args a) {
         unsigned minkey = kNoKey;
         for (int w = 0; w < kWaves; ++w) minkey = min(minkey, sl->wa[w]);
         unsigned ncand = 0;
-        vq = solve_v1(a, xrow, n_sub, minkey, sl, &ncand);
+        vq = solve_v1<VEC>(a, xrow, n_sub, minkey, sl, &ncand);
         if (a.status && tid == 0) a.status[row] = (int)ncand;
       }
       if (q == 1 && a.scheme == LSQ_SCHEME_LST) vq = lds->sv[0];
@@ -776,6 +1119,7 @@ __global__ __launch_bounds__(kThreads) void act_quant_kernel(Args a) {
     if (tid == 0 && !a.forced) lds->sv[q] = vq;
     __syncthreads();
   }
+  LSQ_MARK(9);
   if (tid < a.k) {
     if (a.scales) a.scales[(long long)tid * a.N + row] = lds->sv[tid];
   }
@@ -856,3 +1200,9 @@ extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip,
   a.scales = v12;
   return launch<1>(a, true, (hipStream_t)stream);
 }
+
+#ifdef LSQ_PHASE_CLOCKS
+extern "C" int lsq_debug_read_clocks(long long* host32) {
+  return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(lsq::g_phase_clocks), 32 * sizeof(long long));
+}
+#endif

@@ -108,11 +108,47 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+_timing = None
+
+
+def enable_timing(on: bool = True) -> None:
+    global _timing
+    _timing = {} if on else None
+
+
+def drain_timing():
+    """{kernel: (launches, total_ms, total_algorithmic_bytes)}; call after torch.cuda.synchronize()."""
+    out = {}
+    for name, recs in (_timing or {}).items():
+        out[name] = (len(recs), sum(s.elapsed_time(e) for s, e, _ in recs), sum(b for _, _, b in recs))
+        recs.clear()
+    return out
+
+
+class _Timed:
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        if _timing is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            self.e.record()
+            _timing.setdefault(self.name, []).append((self.s, self.e, self.nbytes))
+
+
 def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, alpha: float,
               planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None) -> None:
     x = _f32c(x)
-    check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha), ptr(forced),
-                              planes.data_ptr(), scales.data_ptr(), stream_ptr()), 'lsq_act_quant')
+    m = geom.C * geom.H * geom.W
+    with _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8)):     # x read once + k bit planes written
+        check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha), ptr(forced),
+                                  planes.data_ptr(), scales.data_ptr(), stream_ptr()), 'lsq_act_quant')
 
 
 def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0):
@@ -151,9 +187,11 @@ def out_hw(geom: ConvGeom):
 
 def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: torch.Tensor, wsum: torch.Tensor,
                 wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
-    check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
-                                wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(),
-                                stream_ptr()), 'lsq_xnor_conv2d')
+    m = geom.C * geom.H * geom.W
+    with _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel()):   # bit planes read + fp32 output written
+        check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
+                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(),
+                                    stream_ptr()), 'lsq_xnor_conv2d')
 
 
 def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark over the 16 ResNet-18 QuantConv2d layer shapes.
+
+    python scripts/kbench.py [--batch 256] [--scheme ls-2] [--iters 20]
+
+Prints, per distinct layer shape, the launch time of lsq_act_quant and lsq_xnor_conv2d measured
+with HIP events on the launch stream, the algorithmic GB/s of the quantizer and the binary
+GMAC/s of the convolution.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'ml-quant_amd')]
+import torch  # noqa: E402
+from quant import _hip  # noqa: E402
+
+SHAPES = [  # (C, H, O, stride, count in ResNet-18)
+    (64, 56, 64, 1, 4), (64, 56, 128, 2, 1), (128, 28, 128, 1, 3), (128, 28, 256, 2, 1),
+    (256, 14, 256, 1, 3), (256, 14, 512, 2, 1), (512, 7, 512, 1, 3)]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in evs)
+    return ts[len(ts) // 2] * 1e3   # median, us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--scheme', default='ls-2')
+    ap.add_argument('--iters', type=int, default=20)
+    args = ap.parse_args()
+    dev = 'cuda:0'
+    sch = {'ls-1': (1, 1), 'ls-2': (2, 2), 'ls-T': (3, 2), 'gf-2': (4, 2)}[args.scheme]
+    n = args.batch
+    tot_q = tot_c = 0.0
+    for c, h, o, stride, count in SHAPES:
+        x = torch.randn(n, c, h, h, device=dev)
+        w = torch.randn(o, c, 3, 3, device=dev)
+        g = _hip.make_geom(n, c, h, h, o, 3, 3, (stride, stride), (1, 1), (1, 1), 1)
+        k = sch[1]
+        planes = torch.zeros(k * _hip.act_plane_words(g), dtype=torch.int64, device=dev)
+        scales = torch.empty((k, n), device=dev)
+        wsc = w.abs().mean(dim=(1, 2, 3)).view(1, -1).contiguous()
+        wbits, wsum = _hip.pack_weight(w, g, wsc)
+        ho, wo = _hip.out_hw(g)
+        y = torch.empty((n, o, ho, wo), device=dev)
+        bias = torch.zeros(o, device=dev)
+        tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales), args.iters)
+        tc = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), args.iters)
+        m = c * h * h
+        qbytes = n * (4 * m + k * m // 8)
+        macs = n * o * ho * wo * c * 9 * k
+        print(f'C={c:4d} H={h:3d} O={o:4d} s={stride}  act_quant {tq:8.1f} us  {qbytes / tq / 1e3:7.1f} GB/s alg | '
+              f'xnor_conv {tc:8.1f} us  {macs / tc / 1e6:9.1f} T binary-MAC/s   (x{count})')
+        tot_q += tq * count
+        tot_c += tc * count
+    print(f'per forward (16 layers, batch {n}): act_quant {tot_q / 1e3:.2f} ms, xnor_conv {tot_c / 1e3:.2f} ms '
+          f'=> path-only {n / ((tot_q + tot_c) * 1e-6):.0f} images/s')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Developer tool: per-phase cycle stamps of lsq_act_quant's workgroup 0 (needs a library built with
+`make -C ml-quant_amd/csrc EXTRA=-DLSQ_PHASE_CLOCKS`)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'ml-quant_amd')]
+import torch
+from quant import _hip
+lib = _hip.lib()
+names = {0: 'start', 1: 'pass0 done', 2: 'solve entry', 3: 'L1 scan+flag done', 4: 'gather done', 5: 'wave path done',
+         6: 'block path done', 8: 'pass1 done', 9: 'end'}
+for c, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
+    n = 256
+    x = torch.randn(n, c, h, h, device='cuda')
+    g = _hip.make_geom(n, c, h, h, c, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+    planes = torch.zeros(2 * _hip.act_plane_words(g), dtype=torch.int64, device='cuda')
+    scales = torch.empty((2, n), device='cuda')
+    for _ in range(3):
+        _hip.act_quant(x, g, 2, 2, 3, 3.0, planes, scales)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 32)()
+    lib.lsq_debug_read_clocks(buf)
+    t0 = buf[0]
+    print(f'C={c} H={h}: ' + ', '.join(f'{names[i]}={buf[i] - t0}' for i in sorted(names) if buf[i]))

@@ -177,3 +177,47 @@ def test_quant_conv2d_lenet_geometry_and_edge_cases(golden):
     y = P.quant_conv2d(x, wg, bg, 'ls-2', 'ls-1', [g['geo_w_v1']], {'kind': 'symmetric', 'alpha': 2},
                        (2, 1), (2, 1), (2, 1), 2)
     assert torch.equal(y, g['geo_y'])
+
+
+# ------------------------------------------------------------------------------------------------
+def _product_model(kind, arch, seed):
+    """Parameters come from the product's module tree only for their names/shapes (detgen fills them)."""
+    from quant.binary.binary_conv import QuantConv2d
+    from quant.models.lenet import QLeNet5
+    from quant.models.resnet import QResNet
+    cls = QResNet if kind == 'resnet' else QLeNet5
+    model = cls(loss_fn=None, **arch)
+    detgen.fill_module(model, seed=seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, QuantConv2d) and hasattr(m.w_approximate, 'v1'):
+                for buf, v in zip(m.w_approximate.cached_scales(), P.weight_scales(m.weight, m.w_quant)):
+                    buf.copy_(v)
+    return model.eval()
+
+
+@pytest.mark.parametrize('tag,shape', [('imagenet_ls1w_ls2a', (2, 3, 64, 64)), ('imagenet_ls1w_fpa', (2, 3, 64, 64)),
+                                       ('imagenet_ls1w_lsTa', (2, 3, 64, 64)), ('imagenet_ls1w_gf2a', (2, 3, 64, 64)),
+                                       ('cifar100_ls1', (4, 3, 32, 32))])
+def test_resnet_oracle_logits_bit_exact(golden, tag, shape):
+    from oracle import ref_models as RMo
+    g = golden('f6_models')
+    arch = g.json(tag + '_arch')
+    sd = {k: v.detach() for k, v in _product_model('resnet', arch, 1).state_dict().items()}
+    scales = {}
+    y = RMo.resnet_forward(sd, arch, detgen.normal(tag + '.x', shape), scales_out=scales)
+    assert torch.equal(y, g[tag + '_logits']), tag
+    for name, sc in scales.items():
+        key = f'{tag}_scales_{name}'
+        if key in g:
+            assert torch.equal(torch.stack(sc), g[key]), key
+
+
+@pytest.mark.parametrize('tag', ['mnist_ls1w_fpa', 'mnist_ls1', 'mnist_ls1w_ls2a'])
+def test_lenet_oracle_bit_exact(golden, tag):
+    from oracle import ref_models as RMo
+    g = golden('f7_lenet')
+    arch = g.json(tag + '_arch')
+    sd = {k: v.detach() for k, v in _product_model('lenet', arch, 3).state_dict().items()}
+    y = RMo.lenet_forward(sd, arch, detgen.normal(tag + '.x', (64, 1, 28, 28)))
+    assert torch.equal(y, g[tag + '_logp']), tag
