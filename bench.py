@@ -96,12 +96,10 @@ def main():
     x = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)       # resident in HBM before timing
     gathered = torch.empty((world * args.batch, 1000), dtype=torch.float32, device=device) if world > 1 else None
 
+    from quant.common.sharded_eval import evaluate_sharded
+
     def step():
-        with torch.no_grad():
-            logits = model(x)
-            if world > 1:
-                dist.all_gather_into_tensor(gathered, logits)
-        return logits
+        return evaluate_sharded(model, x, gathered)       # local forward + RCCL all-gather of logits
 
     for _ in range(args.warmup):
         step()
