@@ -91,10 +91,15 @@ int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
  *                activation_quantization.py:90-98)
  *   planes       out, [k] activation planes laid out as described above (halo pre-zeroed)
  *   scales       out, [k][N] fp32: v1..vk per sample (LST: row 1 repeats v1)
+ *   workspace    lsq_solver_workspace_bytes(N) bytes, 8-byte aligned (LS2 / LST without forced scales)
  */
 int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
                   float clamp_alpha, const float* forced, uint64_t* planes, float* scales,
-                  void* stream);
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Bytes of scratch the LS2 / LST scale solve needs for `rows` rows (slot records handed from the
+ * histogram sweep to the solve kernel).  Not needed (may be NULL / 0) for LS1, GF or forced scales. */
+int64_t lsq_solver_workspace_bytes(int64_t rows);
 
 /*
  * Stand-alone optimal-v1 solve on a dense [R][M] fp32 matrix (rows need not be activations):
@@ -104,7 +109,8 @@ int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int
  *   number of distinct candidate values found (0 => v1 = 0, the reference's zero padding wins).
  */
 int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,
-                   float clamp_alpha, float* v12, int32_t* status, void* stream);
+                   float clamp_alpha, float* v12, int32_t* status, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /*
  * Weight sign packing with cached per-output-channel scales (eval mode):

@@ -59,6 +59,25 @@ __device__ __forceinline__ bool better(const Best& a, const Best& b) {
   return a.cost < b.cost || (a.cost == b.cost && a.order < b.order);
 }
 
+struct Args {
+  const float* x;
+  long long row_elems;      // M = C*H*W (or M of the flat matrix)
+  int C, H, W, cg, Gg, Gt, Hp, Wp, pad_h, pad_w;
+  int scheme, k, skip;
+  float alpha;
+  const float* forced;      // [k][N] or null
+  unsigned long long* planes;
+  long long plane_words;    // words of one plane (all rows)
+  long long row_words;      // words of one row of one plane
+  float* scales;            // [k][N]
+  int* status;              // flat mode: number of candidates per row
+  int N;
+  int flat;                 // 1: dense [R][M] rows, no planes
+  int ternary;
+  int write_scale;          // sweep kernels: store mean|residual| as scale q
+  unsigned char* ws;        // workspace (kWsRow bytes per row)
+};
+
 struct Slot1 {
   unsigned short bin, next_bin;   // next_bin = 0xFFFF: none
   unsigned cnt, r0, succ;         // succ: smallest key above the bin (kNoKey until known)
@@ -104,29 +123,37 @@ struct SolverLds {
   unsigned minkey;
   double total;
   float sv[LSQ_MAX_PLANES];
+  Args args;                  // one copy per workgroup: non-inlined phases read it from LDS
 };
 
 struct SmallLds {
   double ws[kWaves];
   float sv[LSQ_MAX_PLANES];
+  Args args;
 };
 
-struct Args {
-  const float* x;
-  long long row_elems;      // M = C*H*W (or M of the flat matrix)
-  int C, H, W, cg, Gg, Gt, Hp, Wp, pad_h, pad_w;
-  int scheme, k, skip;
-  float alpha;
-  const float* forced;      // [k][N] or null
-  unsigned long long* planes;
-  long long plane_words;    // words of one plane (all rows)
-  long long row_words;      // words of one row of one plane
-  float* scales;            // [k][N]
-  int* status;              // flat mode: number of candidates per row
-  int N;
-  int flat;                 // 1: dense [R][M] rows, no planes
-  int ternary;
+// first sweep of a solver scheme: level-1 histogram, its scan, and the slot records handed to the
+// solve kernel through the workspace
+struct SweepLds {
+  unsigned long long hist1[L1_BINS];
+  unsigned short nzlist[L1_BINS];
+  Slot1 slot[kSlotCap];
+  unsigned wa[kWaves], wb[kWaves], wc[kWaves];
+  double ws[kWaves];
+  double total;
+  float sv[LSQ_MAX_PLANES];
+  Args args;
 };
+
+// per-row record in the caller-provided workspace (sweep kernel -> solve kernel)
+struct RowHeader {
+  unsigned tflag, minkey, n, pad;
+  double total, pad2;
+};
+constexpr long long kWsSlots = sizeof(RowHeader);
+constexpr long long kWsHist = kWsSlots + (long long)kSlotCap * (long long)sizeof(Slot1);
+constexpr long long kWsRow = (kWsHist + (long long)L1_BINS * 8 + 63) / 64 * 64;
+
 
 // exact sum of a histogram bin whose keys share `hi_key` above the low bits
 __device__ __forceinline__ double bin_sum_exact(unsigned hi_key, unsigned cnt, unsigned long long lowsum) {
@@ -328,6 +355,21 @@ __device__ __forceinline__ void chain_eval(const Chain& ch, float xv, bool& bit,
   }
 }
 
+struct PassOut {
+  double sum;
+  unsigned minkey;
+};
+
+template <class L>
+__device__ __forceinline__ Chain load_chain(const L* lds, int q) {
+  Chain ch;
+  ch.q = q;
+#pragma unroll
+  for (int i = 0; i < LSQ_MAX_PLANES; ++i)
+    ch.v[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lds->sv[i])));
+  return ch;
+}
+
 // Which of VEC consecutive elements (flat index = base, base+1, ...) belong to the sub-sample
 // flat % skip == 0 (optimal.py:134)?  `rem` = base % skip.  For the reference's skip = 3 the answer is
 // a select, not a per-element modulo + branch: exactly one of the first three elements is a hit.
@@ -406,8 +448,9 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
 }
 
 template <int VEC, bool HIST, int QM, class L>
-__device__ void pack_pass(const Args& a, const float* __restrict__ xrow, unsigned long long* __restrict__ prow,
-                          const Chain& ch, double& sum_out, unsigned& minkey_out, L* lds) {
+__device__ __forceinline__ PassOut pack_pass(L* lds, const float* __restrict__ xrow, unsigned long long* __restrict__ prow, int q) {
+  const Args a = lds->args;              // registers (SGPRs): nothing below re-reads LDS for it
+  const Chain ch = load_chain(lds, q);
   const unsigned skip = (unsigned)a.skip;
   double acc = 0.0;
   unsigned mk = kNoKey;
@@ -449,14 +492,17 @@ __device__ void pack_pass(const Args& a, const float* __restrict__ xrow, unsigne
           prow[((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w] = word[v];
         }
       });
-  sum_out = acc;
-  minkey_out = mk;
+  PassOut out;
+  out.sum = acc;
+  out.minkey = mk;
+  return out;
 }
 
 // flat rows (no planes): sum |residual| and optional histogram, coalesced
 template <bool HIST, int QM, class L>
-__device__ void flat_pass(const Args& a, const float* __restrict__ xrow, const Chain& ch, double& sum_out,
-                          unsigned& minkey_out, L* lds) {
+__device__ __forceinline__ PassOut flat_pass(L* lds, const float* __restrict__ xrow, int q) {
+  const Args a = lds->args;
+  const Chain ch = load_chain(lds, q);
   const long long M = a.row_elems;
   const unsigned skip = (unsigned)a.skip;
   double acc = 0.0;
@@ -475,8 +521,10 @@ __device__ void flat_pass(const Args& a, const float* __restrict__ xrow, const C
       }
     }
   }
-  sum_out = acc;
-  minkey_out = mk;
+  PassOut out;
+  out.sum = acc;
+  out.minkey = mk;
+  return out;
 }
 
 // sub-sampled keys of the row (optimal.py:134), straight from memory (L2 / Infinity Cache)
@@ -498,456 +546,509 @@ __device__ __forceinline__ void for_each_row_key(const Args& a, const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// The solve.  On entry hist1 holds the level-1 histogram of the n sub-sampled keys.
+// The solve.  On entry hist1 holds the level-1 histogram of the n sub-sampled keys.  The phases are
+// separate non-inlined functions on purpose: each gets its own register allocation, so the rarely
+// used block-level path cannot push the streaming sweeps of the kernel into scratch.
+// level 1: scan the 4096-bin histogram (4 bins per thread), flag bins that may hold a candidate, and
+// write a slot record for the flagged bins with ordinal in [round0, round0 + kSlotCap)
+template <class L>
+__device__ __forceinline__ unsigned l1_scan(L* lds, unsigned n, unsigned round0) {
+  const float* xrow = nullptr;
+  const Args& a = lds->args;
+  const unsigned* list = nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool ternary = a.ternary != 0;
+  double total = 0.0;
+  (void)a; (void)xrow; (void)n; (void)list; (void)tid; (void)lane; (void)wid; (void)ternary;
+  unsigned cnt[4];
+  double sum[4];
+  unsigned my_nz = 0, my_cnt = 0;
+  double my_sum = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned b = 4u * tid + u;
+    const unsigned long long h = lds->hist1[b];
+    cnt[u] = (unsigned)(h >> 42);
+    sum[u] = cnt[u] ? bin_sum_exact(b << L1_SHIFT, cnt[u], h & kLowMask) : 0.0;
+    my_nz += cnt[u] ? 1u : 0u;
+    my_cnt += cnt[u];
+    my_sum += sum[u];
+  }
+  unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
+  double esum = my_sum;
+  block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
+  {
+    unsigned z = enz;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (cnt[u]) lds->nzlist[z++] = (unsigned short)(4u * tid + u);
+  }
+  __syncthreads();
+  unsigned my_flags = 0;
+  bool flag[4];
+  unsigned short nxt[4];
+  {
+    unsigned z = enz, c = ecnt;
+    double s = esum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      flag[u] = false;
+      nxt[u] = 0xFFFFu;
+      if (cnt[u]) {
+        const unsigned b = 4u * tid + u;
+        const double vlo = (double)key_value(b << L1_SHIFT);
+        const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        double next_hi = vhi;
+        if (z + 1 < tnz) {
+          nxt[u] = lds->nzlist[z + 1];
+          next_hi = (double)key_value(((unsigned)nxt[u] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        }
+        flag[u] = n >= 3u && may_hold_candidate(c, cnt[u], s, sum[u], vlo, vhi, next_hi, n, total, ternary);
+        my_flags += flag[u] ? 1u : 0u;
+        ++z;
+      }
+      c += cnt[u];
+      s += sum[u];
+    }
+  }
+  unsigned eflag = my_flags, dummy = 0, tflag, tdummy;
+  double dzero = 0.0, tdz;
+  block_excl_scan(eflag, dummy, dzero, tflag, tdummy, tdz, lds);
+  {
+    unsigned ord = eflag, c = ecnt;
+    double s = esum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (flag[u]) {
+        if (ord >= round0 && ord < round0 + (unsigned)kSlotCap) {
+          Slot1 sl;
+          sl.bin = (unsigned short)(4u * tid + u);
+          sl.next_bin = nxt[u];
+          sl.cnt = cnt[u];
+          sl.r0 = c;
+          sl.succ = kNoKey;
+          sl.base = 0;
+          sl.pad = 0;
+          sl.p0 = s;
+          sl.sum = sum[u];
+          lds->slot[ord - round0] = sl;
+        }
+        ++ord;
+      }
+      c += cnt[u];
+      s += sum[u];
+    }
+  }
+  if (tid == 0) lds->total = total;
+  __syncthreads();
+  return tflag;
+}
+
+// block-level refinement of one slot: levels 2 (10 bits) and 3 (9 bits) as histograms.  Fully general
+// (any count, any ties) but costs ~15 workgroup barriers, so it only serves what the wave-level path
+// gives up on.  from_row: histogram straight from the row (bins too large for the LDS list);
+// otherwise from the slot's segment of the list.
+__device__ __noinline__ Best resolve_slot_block(SolverLds* lds, const float* __restrict__ xrow, unsigned n, unsigned si,
+                                               bool from_row, Best best) {
+  const Args& a = lds->args;
+  unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool ternary = a.ternary != 0;
+  const double total = lds->total;
+  (void)a; (void)xrow; (void)n; (void)list; (void)tid; (void)lane; (void)wid; (void)ternary;
+  const Slot1 s1 = lds->slot[si];
+  const unsigned s1_bin = s1.bin;
+  const unsigned s1_next = s1.next_bin == 0xFFFFu ? kNoKey : (unsigned)s1.next_bin;
+  __syncthreads();
+  for (int i = tid; i < L2_BINS; i += kThreads) lds->u.blk.hist2[i] = 0ull;
+  if (tid == 0) lds->blk_succ = s1.succ;
+  __syncthreads();
+  auto l2 = [&](unsigned key) {
+    const unsigned b = key >> L1_SHIFT;
+    if (b == s1_bin)
+      atomicAdd(&lds->u.blk.hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
+                kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
+    else if (from_row && b == s1_next && key < lds->blk_succ)
+      atomicMin(&lds->blk_succ, key);
+  };
+  if (from_row) {
+    for_each_row_key(a, xrow, n, l2);
+  } else {
+    for (unsigned i = tid; i < s1.cnt; i += kThreads) l2(list[s1.base + i]);
+  }
+  __syncthreads();
+  const unsigned succ_b = lds->blk_succ;
+  // thread t owns sub-bin t
+  const unsigned long long h2 = lds->u.blk.hist2[tid];
+  const unsigned c2 = (unsigned)(h2 >> 42);
+  const unsigned hi_key2 = (s1_bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
+  const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
+  unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
+  double es2 = s2, ts2;
+  block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
+  if (c2) lds->nzlist[enz2] = (unsigned short)tid;   // level-1 use of nzlist is over
+  __syncthreads();
+  const unsigned r02 = s1.r0 + ec2;
+  const double p02 = s1.p0 + es2;
+  unsigned next_sub = kNoKey;
+  bool f2 = false;
+  if (c2) {
+    const double vlo = (double)key_value(hi_key2);
+    const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
+    double next_hi = vhi;
+    if (enz2 + 1 < tnz2) {
+      next_sub = lds->nzlist[enz2 + 1];
+      next_hi = (double)key_value((s1_bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
+    } else if (succ_b != kNoKey) {
+      next_hi = (double)key_value(succ_b);
+    }
+    f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, total, ternary);
+  }
+  unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
+  double dz2 = 0.0, tdz2;
+  block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
+
+  // ---- level 3 in batches of kSeg3 flagged sub-bins
+  for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
+    const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
+    __syncthreads();
+    if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
+      Seg3 g;
+      g.pref = (s1_bin << 10) | (unsigned)tid;
+      g.next_pref = next_sub != kNoKey ? ((s1_bin << 10) | next_sub) : kNoKey;
+      g.cnt = c2;
+      g.r0 = r02;
+      g.p0 = p02;
+      lds->seg[ef2 - b3] = g;
+      lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
+    }
+    for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->u.blk.hist3[0][0])[i] = 0u;
+    __syncthreads();
+    auto l3 = [&](unsigned key) {
+      const unsigned p = key >> L2_SHIFT;
+      for (unsigned j = 0; j < nseg; ++j) {
+        if (p == lds->seg[j].pref)
+          atomicAdd(&lds->u.blk.hist3[j][key & (L3_BINS - 1)], 1u);
+        else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
+          atomicMin(&lds->succ3[j], key);
+      }
+    };
+    if (from_row) {
+      for_each_row_key(a, xrow, n, l3);
+    } else {
+      for (unsigned i = tid; i < s1.cnt; i += kThreads) l3(list[s1.base + i]);
+    }
+    __syncthreads();
+    // wave j resolves segment j: lane owns 8 consecutive keys
+    if ((unsigned)wid < nseg) {
+      const Seg3 g = lds->seg[wid];
+      const unsigned succ_s = lds->succ3[wid];
+      unsigned kc[8];
+      unsigned lane_cnt = 0;
+      double lane_sum = 0.0;
+      unsigned first_key = kNoKey;
+#pragma unroll
+      for (int u = 7; u >= 0; --u) {
+        kc[u] = lds->u.blk.hist3[wid][lane * 8 + u];
+        if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        lane_cnt += kc[u];
+        lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u));
+      }
+      const unsigned ic = wave_incl_scan(lane_cnt);
+      const double is = wave_incl_scan(lane_sum);
+      unsigned after = kNoKey;          // next non-empty key in a higher lane
+      {
+        unsigned sfx = first_key;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const unsigned o = __shfl_down(sfx, d);
+          if (lane + d < 64) sfx = min(sfx, o);
+        }
+        const unsigned up1 = __shfl_down(sfx, 1);
+        after = lane < 63 ? up1 : kNoKey;
+      }
+      unsigned run_r0 = g.r0 + (ic - lane_cnt);
+      double run_p0 = g.p0 + (is - lane_sum);
+      unsigned nextk[8];
+      unsigned cur = after != kNoKey ? after : succ_s;
+#pragma unroll
+      for (int u = 7; u >= 0; --u) {
+        nextk[u] = cur;
+        if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kc[u]) {
+          const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+          const double v = (double)key_value(key);
+          const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
+          if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, total, ternary)) {
+            Best c;
+            c.cost = cost_of(v, run_r0, run_p0, kc[u], n, total, ternary);
+            c.order = run_r0;
+            c.value = key_value(key);
+            if (better(c, best)) best = c;
+            atomicAdd(&lds->n_cand, 1u);
+          }
+          run_r0 += kc[u];
+          run_p0 += (double)kc[u] * v;
+        }
+      }
+    }
+  }
+  return best;
+}
+
+// wave-level refinement of one slot whose keys sit in list[base, base+cnt): 256-way histogram of key
+// bits [18:11] private to the wave, then every flagged sub-bin is either a run of equal keys (resolved
+// analytically) or has <= 64 keys (ranked by brute force with shuffles).  No workgroup barrier: the 16
+// waves resolve 16 slots concurrently.  Returns false to hand the slot to resolve_slot_block.
+struct WaveOut {
+  Best best;
+  int ok;
+};
+
+__device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n, unsigned si, Best best) {
+  const float* xrow = nullptr;
+  const Args& a = lds->args;
+  unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool ternary = a.ternary != 0;
+  const double total = lds->total;
+  (void)a; (void)xrow; (void)n; (void)list; (void)tid; (void)lane; (void)wid; (void)ternary;
+  const Slot1 s1 = lds->slot[si];
+  const unsigned s1_bin = s1.bin;
+  const unsigned succ_b = s1.succ;
+  const unsigned* const seg = list + s1.base;
+  const unsigned seg_n = s1.cnt;
+  unsigned long long* const h = lds->u.whist[wid];
+  unsigned* const wk = lds->wkeys[wid];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) h[lane * 4 + u] = 0ull;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (unsigned i = lane; i < seg_n; i += kWave) {
+    const unsigned key = seg[i];
+    atomicAdd(&h[(key >> kWaveShift) & (kWaveSub - 1)], kOne | (unsigned long long)(key & ((1u << kWaveShift) - 1u)));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  unsigned c[4], lane_cnt = 0, first_sub = kNoKey;
+  double sm[4], lane_sum = 0.0;
+#pragma unroll
+  for (int u = 3; u >= 0; --u) {
+    const unsigned long long hv = h[lane * 4 + u];
+    c[u] = (unsigned)(hv >> 42);
+    const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
+    sm[u] = c[u] ? bin_sum_exact(hi_key, c[u], hv & kLowMask) : 0.0;
+    if (c[u]) first_sub = (unsigned)(lane * 4 + u);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    lane_cnt += c[u];
+    lane_sum += sm[u];
+  }
+  const unsigned ic = wave_incl_scan(lane_cnt);
+  const double is = wave_incl_scan(lane_sum);
+  unsigned after = kNoKey;                      // first non-empty sub-bin in a higher lane
+  {
+    unsigned sfx = first_sub;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_down(sfx, d);
+      if (lane + d < 64) sfx = min(sfx, o);
+    }
+    const unsigned up1 = __shfl_down(sfx, 1);
+    after = lane < 63 ? up1 : kNoKey;
+  }
+  unsigned nsub[4], r0s[4];
+  double p0s[4];
+  bool fl[4];
+  {
+    unsigned cur = after;
+#pragma unroll
+    for (int u = 3; u >= 0; --u) {
+      nsub[u] = cur;
+      if (c[u]) cur = (unsigned)(lane * 4 + u);
+    }
+    unsigned rr = s1.r0 + (ic - lane_cnt);
+    double pp = s1.p0 + (is - lane_sum);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r0s[u] = rr;
+      p0s[u] = pp;
+      rr += c[u];
+      pp += sm[u];
+      fl[u] = false;
+      if (c[u]) {
+        const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
+        const double vlo = (double)key_value(hi_key);
+        const double vhi = (double)key_value(hi_key | ((1u << kWaveShift) - 1u));
+        double next_hi = vhi;
+        if (nsub[u] != kNoKey)
+          next_hi = (double)key_value((s1_bin << L1_SHIFT) | (nsub[u] << kWaveShift) | ((1u << kWaveShift) - 1u));
+        else if (succ_b != kNoKey)
+          next_hi = (double)key_value(succ_b);
+        fl[u] = may_hold_candidate(r0s[u], c[u], p0s[u], sm[u], vlo, vhi, next_hi, n, total, ternary);
+      }
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    unsigned long long todo = __ballot(fl[u]);
+    while (todo) {                               // wave-uniform loop over flagged sub-bins
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const unsigned sub = (unsigned)(src * 4 + u);
+      const unsigned cc = __shfl(c[u], src);
+      const unsigned rs = __shfl(r0s[u], src);
+      const double ps = __shfl(p0s[u], src);
+      const unsigned ns = __shfl(nsub[u], src);
+      const unsigned pref = (s1_bin << 8) | sub;
+      const unsigned npref = ns != kNoKey ? ((s1_bin << 8) | ns) : kNoKey;
+      // one sweep of the segment: this sub-bin's keys (first 64) + its min/max + successor key
+      unsigned pos = 0, succ_l = kNoKey, kmin = kNoKey, kmax = 0u;
+      for (unsigned i0 = 0; i0 < seg_n; i0 += kWave) {
+        const unsigned i = i0 + lane;
+        const unsigned key = i < seg_n ? seg[i] : kNoKey;
+        const unsigned pk = key >> kWaveShift;
+        const bool mine = i < seg_n && pk == pref;
+        const unsigned long long mm = __ballot(mine);
+        if (mine) {
+          const unsigned at = pos + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+          if (at < (unsigned)kWave) wk[at] = key;
+          kmin = min(kmin, key);
+          kmax = max(kmax, key);
+        }
+        pos += (unsigned)__popcll(mm);
+        if (i < seg_n && pk == npref) succ_l = min(succ_l, key);
+      }
+      const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : succ_b;
+      const double succ_v = succ_k != kNoKey ? (double)key_value(succ_k) : INFINITY;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (cc > (unsigned)kWave) {
+        kmin = wave_min(kmin);
+        kmax = ~wave_min(~kmax);
+        if (kmin != kmax) {
+          ok = false;                            // many distinct keys in one sub-bin: block path
+          continue;
+        }
+        // a run of cc equal keys (saturated clamp value, exact zeros, constant rows)
+        const double v = (double)key_value(kmin);
+        if (run_has_candidate(v, cc, rs, ps, succ_v, n, total, ternary)) {
+          Best cb;
+          cb.cost = cost_of(v, rs, ps, cc, n, total, ternary);
+          cb.order = rs;
+          cb.value = key_value(kmin);
+          if (better(cb, best)) best = cb;
+          if (lane == 0) atomicAdd(&lds->n_cand, 1u);
+        }
+        continue;
+      }
+      const bool act = (unsigned)lane < cc;
+      const unsigned key = act ? wk[lane] : kNoKey;
+      unsigned rank = 0, below = 0, eq = 0;
+      double bsum = 0.0, psum = 0.0;
+      for (unsigned j = 0; j < cc; ++j) {
+        const unsigned kj = __shfl(key, (int)j);
+        const double vj = (double)key_value(kj);
+        const bool lt = kj < key, e = kj == key;
+        below += lt ? 1u : 0u;
+        eq += e ? 1u : 0u;
+        if (lt) bsum += vj;
+        if (lt || (e && j <= (unsigned)lane)) psum += vj;
+        if (lt || (e && j < (unsigned)lane)) ++rank;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (act) wk[rank] = key;                   // sorted order
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      bool cand = false;
+      if (act) {
+        const unsigned nk = rank + 1u < cc ? wk[rank + 1u] : succ_k;
+        const double v = (double)key_value(key);
+        const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
+        const long long i = (long long)rs + rank;
+        cand = i >= 1 && i <= (long long)n - 2 &&
+               position_is_candidate(v, nv, (double)(i + 1), ps + psum, (double)n, total, ternary);
+        if (cand) {
+          Best cb;
+          cb.cost = cost_of(v, rs + below, ps + bsum, eq, n, total, ternary);
+          cb.order = rs + below;
+          cb.value = key_value(key);
+          if (better(cb, best)) best = cb;
+        }
+      }
+      const unsigned long long firsts = __ballot(cand && below == rank);
+      if (lane == 0 && firsts) atomicAdd(&lds->n_cand, (unsigned)__popcll(firsts));
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  WaveOut wo;
+  wo.best = best;
+  wo.ok = ok ? 1 : 0;
+  return wo;
+}
+
+// gather sweep: every sub-sampled key of a flagged bin goes to its slot's segment of the LDS list; keys
+// of the bin right above a flagged bin update that slot's successor key.  Activations are re-read with
+// the coalesced full-row sweep (a strided 4-byte gather of the sub-sample alone was slower); dense
+// flat rows use the strided walk.
 template <int VEC>
-__device__ __noinline__ float solve_v1(const Args& a, const float* __restrict__ xrow, unsigned n, unsigned minkey,
-                          SolverLds* lds, unsigned* n_candidates) {
+__device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restrict__ xrow, unsigned n, unsigned sb) {
+  const Args a = lds->args;
+  unsigned* const list = lds->list;
+  auto take = [&](unsigned key) {
+    const unsigned r = lds->role[key >> L1_SHIFT];
+    const unsigned gs = r & 0xFFu, ss = r >> 8;
+    if (gs) {
+      const Slot1* sl = &lds->slot[sb + gs - 1u];
+      list[sl->base + atomicAdd(&lds->fill[gs - 1u], 1u)] = key;
+    }
+    if (ss) {
+      unsigned* sp = &lds->slot[sb + ss - 1u].succ;
+      if (key < *sp) atomicMin(sp, key);
+    }
+  };
+  if (a.flat) {
+    for_each_row_key(a, xrow, n, take);
+  } else {
+    const unsigned skip = (unsigned)a.skip;
+    sweep_row<VEC, true>(
+        a, xrow, []() {},
+        [&](int, const float (&x)[VEC], unsigned rem) {
+          emit_subsample<VEC>(x, rem, skip, [&](float xs) { take(abs_key(xs)); });
+        },
+        [](int, int) {});
+  }
+}
+
+// The solve proper.  On entry the slot records of the flagged level-1 bins are in lds->slot (or, for
+// tflag > kSlotCap, the level-1 histogram is back in lds->hist1) and lds->total is set.
+__device__ __noinline__ unsigned l1_rescan(SolverLds* lds, unsigned n, unsigned round0) { return l1_scan(lds, n, round0); }
+
+template <int VEC>
+__device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restrict__ xrow, unsigned n, unsigned minkey,
+                                          unsigned tflag) {
+  const Args& a = lds->args;
   const bool ternary = a.ternary != 0;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   Best best;
   best.cost = INFINITY;
   best.order = kNoKey;
   best.value = 0.f;
-  if (tid == 0) lds->n_cand = 0;
   unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
-  // every sub-sampled key of the row: coalesced full-row sweep for activations (the strided
-  // 4-byte gather was 2.5x slower than re-reading the whole row), strided for dense flat rows
-  auto sweep_keys = [&](auto&& f) {
-    if (a.flat) {
-      for_each_row_key(a, xrow, n, f);
-    } else {
-      const unsigned skip = (unsigned)a.skip;
-      sweep_row<VEC, true>(
-          a, xrow, []() {},
-          [&](int, const float (&x)[VEC], unsigned rem) {
-            emit_subsample<VEC>(x, rem, skip, [&](float xs) { f(abs_key(xs)); });
-          },
-          [](int, int) {});
-    }
-  };
+  (void)list;
   LSQ_MARK(2);
-
-  // ---- level 1: scan the 4096-bin histogram (4 bins per thread), flag bins that may hold a
-  //      candidate, and write a slot record for the flagged bins with ordinal in [round0, round0+cap)
-  double total = 0.0;
-  auto l1_scan = [&](unsigned round0) -> unsigned {
-    unsigned cnt[4];
-    double sum[4];
-    unsigned my_nz = 0, my_cnt = 0;
-    double my_sum = 0.0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned b = 4u * tid + u;
-      const unsigned long long h = lds->hist1[b];
-      cnt[u] = (unsigned)(h >> 42);
-      sum[u] = cnt[u] ? bin_sum_exact(b << L1_SHIFT, cnt[u], h & kLowMask) : 0.0;
-      my_nz += cnt[u] ? 1u : 0u;
-      my_cnt += cnt[u];
-      my_sum += sum[u];
-    }
-    unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
-    double esum = my_sum;
-    block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
-    {
-      unsigned z = enz;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (cnt[u]) lds->nzlist[z++] = (unsigned short)(4u * tid + u);
-    }
-    __syncthreads();
-    unsigned my_flags = 0;
-    bool flag[4];
-    unsigned short nxt[4];
-    {
-      unsigned z = enz, c = ecnt;
-      double s = esum;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        flag[u] = false;
-        nxt[u] = 0xFFFFu;
-        if (cnt[u]) {
-          const unsigned b = 4u * tid + u;
-          const double vlo = (double)key_value(b << L1_SHIFT);
-          const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
-          double next_hi = vhi;
-          if (z + 1 < tnz) {
-            nxt[u] = lds->nzlist[z + 1];
-            next_hi = (double)key_value(((unsigned)nxt[u] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
-          }
-          flag[u] = n >= 3u && may_hold_candidate(c, cnt[u], s, sum[u], vlo, vhi, next_hi, n, total, ternary);
-          my_flags += flag[u] ? 1u : 0u;
-          ++z;
-        }
-        c += cnt[u];
-        s += sum[u];
-      }
-    }
-    unsigned eflag = my_flags, dummy = 0, tflag, tdummy;
-    double dzero = 0.0, tdz;
-    block_excl_scan(eflag, dummy, dzero, tflag, tdummy, tdz, lds);
-    {
-      unsigned ord = eflag, c = ecnt;
-      double s = esum;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (flag[u]) {
-          if (ord >= round0 && ord < round0 + (unsigned)kSlotCap) {
-            Slot1 sl;
-            sl.bin = (unsigned short)(4u * tid + u);
-            sl.next_bin = nxt[u];
-            sl.cnt = cnt[u];
-            sl.r0 = c;
-            sl.succ = kNoKey;
-            sl.base = 0;
-            sl.pad = 0;
-            sl.p0 = s;
-            sl.sum = sum[u];
-            lds->slot[ord - round0] = sl;
-          }
-          ++ord;
-        }
-        c += cnt[u];
-        s += sum[u];
-      }
-    }
-    __syncthreads();
-    return tflag;
-  };
-
-  // ---- block-level refinement of one slot: levels 2 (10 bits) and 3 (9 bits) as histograms.
-  //      Fully general (any count, any ties) but costs ~15 workgroup barriers, so it only serves
-  //      what the wave-level path gives up on.  from_row: histogram straight from the row (bins too
-  //      large for the LDS list); otherwise from the slot's segment of the list.
-  auto resolve_slot_block = [&](unsigned si, bool from_row) {
-    const Slot1 s1 = lds->slot[si];
-    const unsigned s1_bin = s1.bin;
-    const unsigned s1_next = s1.next_bin == 0xFFFFu ? kNoKey : (unsigned)s1.next_bin;
-    __syncthreads();
-    for (int i = tid; i < L2_BINS; i += kThreads) lds->u.blk.hist2[i] = 0ull;
-    if (tid == 0) lds->blk_succ = s1.succ;
-    __syncthreads();
-    auto l2 = [&](unsigned key) {
-      const unsigned b = key >> L1_SHIFT;
-      if (b == s1_bin)
-        atomicAdd(&lds->u.blk.hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
-                  kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
-      else if (from_row && b == s1_next && key < lds->blk_succ)
-        atomicMin(&lds->blk_succ, key);
-    };
-    if (from_row) {
-      for_each_row_key(a, xrow, n, l2);
-    } else {
-      for (unsigned i = tid; i < s1.cnt; i += kThreads) l2(list[s1.base + i]);
-    }
-    __syncthreads();
-    const unsigned succ_b = lds->blk_succ;
-    // thread t owns sub-bin t
-    const unsigned long long h2 = lds->u.blk.hist2[tid];
-    const unsigned c2 = (unsigned)(h2 >> 42);
-    const unsigned hi_key2 = (s1_bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
-    const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
-    unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
-    double es2 = s2, ts2;
-    block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
-    if (c2) lds->nzlist[enz2] = (unsigned short)tid;   // level-1 use of nzlist is over
-    __syncthreads();
-    const unsigned r02 = s1.r0 + ec2;
-    const double p02 = s1.p0 + es2;
-    unsigned next_sub = kNoKey;
-    bool f2 = false;
-    if (c2) {
-      const double vlo = (double)key_value(hi_key2);
-      const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
-      double next_hi = vhi;
-      if (enz2 + 1 < tnz2) {
-        next_sub = lds->nzlist[enz2 + 1];
-        next_hi = (double)key_value((s1_bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
-      } else if (succ_b != kNoKey) {
-        next_hi = (double)key_value(succ_b);
-      }
-      f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, total, ternary);
-    }
-    unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
-    double dz2 = 0.0, tdz2;
-    block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
-
-    // ---- level 3 in batches of kSeg3 flagged sub-bins
-    for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
-      const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
-      __syncthreads();
-      if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
-        Seg3 g;
-        g.pref = (s1_bin << 10) | (unsigned)tid;
-        g.next_pref = next_sub != kNoKey ? ((s1_bin << 10) | next_sub) : kNoKey;
-        g.cnt = c2;
-        g.r0 = r02;
-        g.p0 = p02;
-        lds->seg[ef2 - b3] = g;
-        lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
-      }
-      for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->u.blk.hist3[0][0])[i] = 0u;
-      __syncthreads();
-      auto l3 = [&](unsigned key) {
-        const unsigned p = key >> L2_SHIFT;
-        for (unsigned j = 0; j < nseg; ++j) {
-          if (p == lds->seg[j].pref)
-            atomicAdd(&lds->u.blk.hist3[j][key & (L3_BINS - 1)], 1u);
-          else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
-            atomicMin(&lds->succ3[j], key);
-        }
-      };
-      if (from_row) {
-        for_each_row_key(a, xrow, n, l3);
-      } else {
-        for (unsigned i = tid; i < s1.cnt; i += kThreads) l3(list[s1.base + i]);
-      }
-      __syncthreads();
-      // wave j resolves segment j: lane owns 8 consecutive keys
-      if ((unsigned)wid < nseg) {
-        const Seg3 g = lds->seg[wid];
-        const unsigned succ_s = lds->succ3[wid];
-        unsigned kc[8];
-        unsigned lane_cnt = 0;
-        double lane_sum = 0.0;
-        unsigned first_key = kNoKey;
-#pragma unroll
-        for (int u = 7; u >= 0; --u) {
-          kc[u] = lds->u.blk.hist3[wid][lane * 8 + u];
-          if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          lane_cnt += kc[u];
-          lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u));
-        }
-        const unsigned ic = wave_incl_scan(lane_cnt);
-        const double is = wave_incl_scan(lane_sum);
-        unsigned after = kNoKey;          // next non-empty key in a higher lane
-        {
-          unsigned sfx = first_key;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const unsigned o = __shfl_down(sfx, d);
-            if (lane + d < 64) sfx = min(sfx, o);
-          }
-          const unsigned up1 = __shfl_down(sfx, 1);
-          after = lane < 63 ? up1 : kNoKey;
-        }
-        unsigned run_r0 = g.r0 + (ic - lane_cnt);
-        double run_p0 = g.p0 + (is - lane_sum);
-        unsigned nextk[8];
-        unsigned cur = after != kNoKey ? after : succ_s;
-#pragma unroll
-        for (int u = 7; u >= 0; --u) {
-          nextk[u] = cur;
-          if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (kc[u]) {
-            const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
-            const double v = (double)key_value(key);
-            const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
-            if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, total, ternary)) {
-              Best c;
-              c.cost = cost_of(v, run_r0, run_p0, kc[u], n, total, ternary);
-              c.order = run_r0;
-              c.value = key_value(key);
-              if (better(c, best)) best = c;
-              atomicAdd(&lds->n_cand, 1u);
-            }
-            run_r0 += kc[u];
-            run_p0 += (double)kc[u] * v;
-          }
-        }
-      }
-    }
-  };
-
-  // ---- wave-level refinement of one slot whose keys sit in list[base, base+cnt): 256-way
-  //      histogram of key bits [18:11] private to the wave, then every flagged sub-bin is either
-  //      a run of equal keys (resolved analytically) or has <= 64 keys (ranked by brute force with
-  //      shuffles).  No workgroup barrier: the 16 waves resolve 16 slots concurrently.  Returns
-  //      false to hand the slot to resolve_slot_block.
-  auto resolve_slot_wave = [&](unsigned si) -> bool {
-    const Slot1 s1 = lds->slot[si];
-    const unsigned s1_bin = s1.bin;
-    const unsigned succ_b = s1.succ;
-    const unsigned* const seg = list + s1.base;
-    const unsigned seg_n = s1.cnt;
-    unsigned long long* const h = lds->u.whist[wid];
-    unsigned* const wk = lds->wkeys[wid];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) h[lane * 4 + u] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (unsigned i = lane; i < seg_n; i += kWave) {
-      const unsigned key = seg[i];
-      atomicAdd(&h[(key >> kWaveShift) & (kWaveSub - 1)], kOne | (unsigned long long)(key & ((1u << kWaveShift) - 1u)));
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    unsigned c[4], lane_cnt = 0, first_sub = kNoKey;
-    double sm[4], lane_sum = 0.0;
-#pragma unroll
-    for (int u = 3; u >= 0; --u) {
-      const unsigned long long hv = h[lane * 4 + u];
-      c[u] = (unsigned)(hv >> 42);
-      const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
-      sm[u] = c[u] ? bin_sum_exact(hi_key, c[u], hv & kLowMask) : 0.0;
-      if (c[u]) first_sub = (unsigned)(lane * 4 + u);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      lane_cnt += c[u];
-      lane_sum += sm[u];
-    }
-    const unsigned ic = wave_incl_scan(lane_cnt);
-    const double is = wave_incl_scan(lane_sum);
-    unsigned after = kNoKey;                      // first non-empty sub-bin in a higher lane
-    {
-      unsigned sfx = first_sub;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned o = __shfl_down(sfx, d);
-        if (lane + d < 64) sfx = min(sfx, o);
-      }
-      const unsigned up1 = __shfl_down(sfx, 1);
-      after = lane < 63 ? up1 : kNoKey;
-    }
-    unsigned nsub[4], r0s[4];
-    double p0s[4];
-    bool fl[4];
-    {
-      unsigned cur = after;
-#pragma unroll
-      for (int u = 3; u >= 0; --u) {
-        nsub[u] = cur;
-        if (c[u]) cur = (unsigned)(lane * 4 + u);
-      }
-      unsigned rr = s1.r0 + (ic - lane_cnt);
-      double pp = s1.p0 + (is - lane_sum);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        r0s[u] = rr;
-        p0s[u] = pp;
-        rr += c[u];
-        pp += sm[u];
-        fl[u] = false;
-        if (c[u]) {
-          const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
-          const double vlo = (double)key_value(hi_key);
-          const double vhi = (double)key_value(hi_key | ((1u << kWaveShift) - 1u));
-          double next_hi = vhi;
-          if (nsub[u] != kNoKey)
-            next_hi = (double)key_value((s1_bin << L1_SHIFT) | (nsub[u] << kWaveShift) | ((1u << kWaveShift) - 1u));
-          else if (succ_b != kNoKey)
-            next_hi = (double)key_value(succ_b);
-          fl[u] = may_hold_candidate(r0s[u], c[u], p0s[u], sm[u], vlo, vhi, next_hi, n, total, ternary);
-        }
-      }
-    }
-    bool ok = true;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      unsigned long long todo = __ballot(fl[u]);
-      while (todo) {                               // wave-uniform loop over flagged sub-bins
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const unsigned sub = (unsigned)(src * 4 + u);
-        const unsigned cc = __shfl(c[u], src);
-        const unsigned rs = __shfl(r0s[u], src);
-        const double ps = __shfl(p0s[u], src);
-        const unsigned ns = __shfl(nsub[u], src);
-        const unsigned pref = (s1_bin << 8) | sub;
-        const unsigned npref = ns != kNoKey ? ((s1_bin << 8) | ns) : kNoKey;
-        // one sweep of the segment: this sub-bin's keys (first 64) + its min/max + successor key
-        unsigned pos = 0, succ_l = kNoKey, kmin = kNoKey, kmax = 0u;
-        for (unsigned i0 = 0; i0 < seg_n; i0 += kWave) {
-          const unsigned i = i0 + lane;
-          const unsigned key = i < seg_n ? seg[i] : kNoKey;
-          const unsigned pk = key >> kWaveShift;
-          const bool mine = i < seg_n && pk == pref;
-          const unsigned long long mm = __ballot(mine);
-          if (mine) {
-            const unsigned at = pos + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
-            if (at < (unsigned)kWave) wk[at] = key;
-            kmin = min(kmin, key);
-            kmax = max(kmax, key);
-          }
-          pos += (unsigned)__popcll(mm);
-          if (i < seg_n && pk == npref) succ_l = min(succ_l, key);
-        }
-        const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : succ_b;
-        const double succ_v = succ_k != kNoKey ? (double)key_value(succ_k) : INFINITY;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (cc > (unsigned)kWave) {
-          kmin = wave_min(kmin);
-          kmax = ~wave_min(~kmax);
-          if (kmin != kmax) {
-            ok = false;                            // many distinct keys in one sub-bin: block path
-            continue;
-          }
-          // a run of cc equal keys (saturated clamp value, exact zeros, constant rows)
-          const double v = (double)key_value(kmin);
-          if (run_has_candidate(v, cc, rs, ps, succ_v, n, total, ternary)) {
-            Best cb;
-            cb.cost = cost_of(v, rs, ps, cc, n, total, ternary);
-            cb.order = rs;
-            cb.value = key_value(kmin);
-            if (better(cb, best)) best = cb;
-            if (lane == 0) atomicAdd(&lds->n_cand, 1u);
-          }
-          continue;
-        }
-        const bool act = (unsigned)lane < cc;
-        const unsigned key = act ? wk[lane] : kNoKey;
-        unsigned rank = 0, below = 0, eq = 0;
-        double bsum = 0.0, psum = 0.0;
-        for (unsigned j = 0; j < cc; ++j) {
-          const unsigned kj = __shfl(key, (int)j);
-          const double vj = (double)key_value(kj);
-          const bool lt = kj < key, e = kj == key;
-          below += lt ? 1u : 0u;
-          eq += e ? 1u : 0u;
-          if (lt) bsum += vj;
-          if (lt || (e && j <= (unsigned)lane)) psum += vj;
-          if (lt || (e && j < (unsigned)lane)) ++rank;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (act) wk[rank] = key;                   // sorted order
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        bool cand = false;
-        if (act) {
-          const unsigned nk = rank + 1u < cc ? wk[rank + 1u] : succ_k;
-          const double v = (double)key_value(key);
-          const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
-          const long long i = (long long)rs + rank;
-          cand = i >= 1 && i <= (long long)n - 2 &&
-                 position_is_candidate(v, nv, (double)(i + 1), ps + psum, (double)n, total, ternary);
-          if (cand) {
-            Best cb;
-            cb.cost = cost_of(v, rs + below, ps + bsum, eq, n, total, ternary);
-            cb.order = rs + below;
-            cb.value = key_value(key);
-            if (better(cb, best)) best = cb;
-          }
-        }
-        const unsigned long long firsts = __ballot(cand && below == rank);
-        if (lane == 0 && firsts) atomicAdd(&lds->n_cand, (unsigned)__popcll(firsts));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      }
-    }
-    return ok;
-  };
-
-  unsigned tflag = l1_scan(0);
   LSQ_MARK(3);
   if (tflag > (unsigned)kSlotCap) {
     // pathological rows (hundreds of crossing bins): no LDS list, so hist1 stays intact and the
     // scan can be repeated for each group of kSlotCap flagged bins
     for (unsigned round0 = 0; round0 < tflag; round0 += kSlotCap) {
-      if (round0) l1_scan(round0);
+      l1_rescan(lds, n, round0);
       const unsigned nslot = min((unsigned)kSlotCap, tflag - round0);
-      for (unsigned si = 0; si < nslot; ++si) resolve_slot_block(si, true);
+      for (unsigned si = 0; si < nslot; ++si) best = resolve_slot_block(lds, xrow, n, si, true, best);
     }
   } else if (tflag) {
     if (tid == 0) {                                 // greedy split by gathered-key capacity
@@ -972,7 +1073,7 @@ __device__ __noinline__ float solve_v1(const Args& a, const float* __restrict__ 
       const unsigned sb = lds->sub_begin[sr], se = lds->sub_begin[sr + 1];
       __syncthreads();
       if (se - sb == 1u && lds->slot[sb].cnt > (unsigned)kListExt) {
-        resolve_slot_block(sb, true);              // one huge bin: histogram straight from the row
+        best = resolve_slot_block(lds, xrow, n, sb, true, best);              // one huge bin: histogram straight from the row
         continue;
       }
       for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->role)[i] = 0u;
@@ -988,41 +1089,31 @@ __device__ __noinline__ float solve_v1(const Args& a, const float* __restrict__ 
       __syncthreads();
       // gather pass: every key of a flagged bin goes to its slot's segment of the LDS list; keys of
       // the bin right above a flagged bin update that slot's successor key
-      auto take = [&](unsigned key) {
-        const unsigned r = lds->role[key >> L1_SHIFT];
-        const unsigned gs = r & 0xFFu, ss = r >> 8;
-        if (gs) {
-          const Slot1* sl = &lds->slot[sb + gs - 1u];
-          list[sl->base + atomicAdd(&lds->fill[gs - 1u], 1u)] = key;
-        }
-        if (ss) {
-          unsigned* sp = &lds->slot[sb + ss - 1u].succ;
-          if (key < *sp) atomicMin(sp, key);
-        }
-      };
-      sweep_keys(take);
+      gather_keys<VEC>(lds, xrow, n, sb);
       __syncthreads();
       LSQ_MARK(4);
       for (unsigned si = sb + (unsigned)wid; si < se; si += kWaves) {
-        if (!resolve_slot_wave(si)) {
+        const WaveOut wo = resolve_slot_wave(lds, n, si, best);
+        best = wo.best;
+        if (!wo.ok) {
           if (lane == 0) lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)si;
         }
       }
       __syncthreads();
       LSQ_MARK(5);
       const unsigned n_slow = lds->n_slow;
-      for (unsigned q = 0; q < n_slow; ++q) resolve_slot_block(lds->slow[q], false);
+      for (unsigned q = 0; q < n_slow; ++q) best = resolve_slot_block(lds, xrow, n, lds->slow[q], false, best);
     }
   }
   LSQ_MARK(6);
 
   // ---- ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
   if (ternary && n > 0u && tid == 0) {
-    const double mean = total / (double)n;
+    const double mean = lds->total / (double)n;
     if ((double)key_value(minkey) > 0.5 * mean) {
       const float half = (float)((double)((float)mean) / 2.0);
       Best c;
-      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, total, true);
+      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, lds->total, true);
       c.order = n + 1u;
       c.value = half;
       if (better(c, best)) best = c;
@@ -1045,91 +1136,133 @@ __device__ __noinline__ float solve_v1(const Args& a, const float* __restrict__ 
   Best r = lds->wbest[0];
   for (int w = 1; w < kWaves; ++w)
     if (better(lds->wbest[w], r)) r = lds->wbest[w];
-  *n_candidates = lds->n_cand;
   return r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int VEC, bool SOLVER>
-__global__ __launch_bounds__(kThreads) void act_quant_kernel(Args a) {
-  using L = typename std::conditional<SOLVER, SolverLds, SmallLds>::type;
+// Kernel A: one streaming sweep of every row: plane q, mean |residual_q| -> scale q, and for the first
+// sweep of a solver scheme the level-1 histogram, its scan and the slot records (-> workspace).
+template <int VEC, bool HIST, int QM>
+__global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
+  using L = typename std::conditional<HIST, SweepLds, SmallLds>::type;
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(L)];
   L* lds = reinterpret_cast<L*>(smem);
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
   const float* xrow = a.x + (long long)row * a.row_elems;
-  const unsigned n_sub = (unsigned)((a.row_elems + a.skip - 1) / a.skip);
-
-  if (SOLVER) {
-    SolverLds* sl = reinterpret_cast<SolverLds*>(smem);
-    for (int i = tid; i < L1_BINS; i += kThreads) sl->hist1[i] = 0ull;
+  if constexpr (HIST) {
+    for (int i = tid; i < L1_BINS; i += kThreads) lds->hist1[i] = 0ull;
   }
-  if (tid < LSQ_MAX_PLANES) lds->sv[tid] = a.forced ? (tid < a.k ? a.forced[(long long)tid * a.N + row] : 0.f) : 0.f;
+  if (tid == 0) lds->args = a;
+  if (tid < LSQ_MAX_PLANES) lds->sv[tid] = tid < q ? a.scales[(long long)tid * a.N + row] : 0.f;
   __syncthreads();
-
-  Chain ch;
   LSQ_MARK(0);
-  for (int q = 0; q < a.k; ++q) {
-    ch.q = q;
-#pragma unroll
-    for (int i = 0; i < LSQ_MAX_PLANES; ++i)
-      ch.v[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lds->sv[i])));
-    double part = 0.0;
-    unsigned mk = kNoKey;
-    const bool hist = SOLVER && q == 0 && !a.forced;
-    unsigned long long* prow = a.flat ? nullptr : a.planes + (long long)q * a.plane_words + (long long)row * a.row_words;
-    if (a.flat) {
-      if (q == 0) {
-        if (hist) flat_pass<SOLVER, 0>(a, xrow, ch, part, mk, lds);
-        else flat_pass<false, 0>(a, xrow, ch, part, mk, lds);
-      } else if (q == 1) {
-        flat_pass<false, 1>(a, xrow, ch, part, mk, lds);
-      } else {
-        flat_pass<false, 2>(a, xrow, ch, part, mk, lds);
-      }
-    } else {
-      if (q == 0) {
-        if (hist) pack_pass<VEC, SOLVER, 0>(a, xrow, prow, ch, part, mk, lds);
-        else pack_pass<VEC, false, 0>(a, xrow, prow, ch, part, mk, lds);
-      } else if (q == 1) {
-        pack_pass<VEC, false, 1>(a, xrow, prow, ch, part, mk, lds);
-      } else {
-        pack_pass<VEC, false, 2>(a, xrow, prow, ch, part, mk, lds);
-      }
-    }
-    LSQ_MARK(1 + 7 * q);
-    const double tot = block_sum(part, lds);
-    float vq = (float)(tot / (double)a.row_elems);
-    if (SOLVER) {
-      if (q == 0 && !a.forced) {
-        SolverLds* sl = reinterpret_cast<SolverLds*>(smem);
-        mk = wave_min(mk);
-        __syncthreads();
-        if ((tid & 63) == 0) sl->wa[tid >> 6] = mk;
-        __syncthreads();
-        unsigned minkey = kNoKey;
-        for (int w = 0; w < kWaves; ++w) minkey = min(minkey, sl->wa[w]);
-        unsigned ncand = 0;
-        vq = solve_v1<VEC>(a, xrow, n_sub, minkey, sl, &ncand);
-        if (a.status && tid == 0) a.status[row] = (int)ncand;
-      }
-      if (q == 1 && a.scheme == LSQ_SCHEME_LST) vq = lds->sv[0];
-    }
+  PassOut po;
+  if (a.flat) {
+    po = flat_pass<HIST, QM>(lds, xrow, q);
+  } else {
+    unsigned long long* prow = a.planes + (long long)q * a.plane_words + (long long)row * a.row_words;
+    po = pack_pass<VEC, HIST, QM>(lds, xrow, prow, q);
+  }
+  LSQ_MARK(1);
+  const double tot = block_sum(po.sum, lds);
+  if (a.write_scale && tid == 0) a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);
+  if constexpr (HIST) {
+    const unsigned n_sub = (unsigned)((a.row_elems + a.skip - 1) / a.skip);
+    const unsigned mk = wave_min(po.minkey);
     __syncthreads();
-    if (tid == 0 && !a.forced) lds->sv[q] = vq;
+    if ((tid & 63) == 0) lds->wa[tid >> 6] = mk;
     __syncthreads();
+    unsigned minkey = kNoKey;
+    for (int w = 0; w < kWaves; ++w) minkey = min(minkey, lds->wa[w]);
+    const unsigned tflag = l1_scan(lds, n_sub, 0);
+    unsigned char* wrow = a.ws + (long long)row * kWsRow;
+    if (tid == 0) {
+      RowHeader h;
+      h.tflag = tflag;
+      h.minkey = minkey;
+      h.n = n_sub;
+      h.pad = 0;
+      h.total = lds->total;
+      h.pad2 = 0.0;
+      *reinterpret_cast<RowHeader*>(wrow) = h;
+    }
+    const unsigned nslot = min(tflag, (unsigned)kSlotCap);
+    const unsigned words = nslot * (unsigned)(sizeof(Slot1) / 4);
+    const unsigned* src = reinterpret_cast<const unsigned*>(lds->slot);
+    unsigned* dst = reinterpret_cast<unsigned*>(wrow + kWsSlots);
+    for (unsigned i = tid; i < words; i += kThreads) dst[i] = src[i];
+    if (tflag > (unsigned)kSlotCap) {           // rare: the solve kernel re-scans the histogram in groups
+      unsigned long long* hd = reinterpret_cast<unsigned long long*>(wrow + kWsHist);
+      for (int i = tid; i < L1_BINS; i += kThreads) hd[i] = lds->hist1[i];
+    }
   }
   LSQ_MARK(9);
-  if (tid < a.k) {
-    if (a.scales) a.scales[(long long)tid * a.N + row] = lds->sv[tid];
+}
+
+// Kernel B: the solve.  Reads the row's slot records, gathers the flagged bins' keys with a second
+// sweep, refines them and writes v1 (ternary: v1 also as the second scale).
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(SolverLds)];
+  SolverLds* lds = reinterpret_cast<SolverLds*>(smem);
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* xrow = a.x + (long long)row * a.row_elems;
+  const unsigned char* wrow = a.ws + (long long)row * kWsRow;
+  const RowHeader h = *reinterpret_cast<const RowHeader*>(wrow);
+  if (tid == 0) {
+    lds->args = a;
+    lds->total = h.total;
+    lds->n_cand = 0;
+  }
+  if (h.tflag > (unsigned)kSlotCap) {
+    const unsigned long long* hs = reinterpret_cast<const unsigned long long*>(wrow + kWsHist);
+    for (int i = tid; i < L1_BINS; i += kThreads) lds->hist1[i] = hs[i];
+  } else {
+    const unsigned words = h.tflag * (unsigned)(sizeof(Slot1) / 4);
+    const unsigned* src = reinterpret_cast<const unsigned*>(wrow + kWsSlots);
+    unsigned* dst = reinterpret_cast<unsigned*>(lds->slot);
+    for (unsigned i = tid; i < words; i += kThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  const float v1 = solve_v1<VEC>(lds, xrow, h.n, h.minkey, h.tflag);
+  if (tid == 0) {
+    a.scales[row] = v1;
+    if (a.ternary) a.scales[(long long)a.N + row] = v1;
+    if (a.status) a.status[row] = (int)lds->n_cand;
   }
 }
 
 template <int VEC>
-int launch(const Args& a, bool solver, hipStream_t st) {
-  if (solver) hipLaunchKernelGGL((act_quant_kernel<VEC, true>), dim3(a.N), dim3(kThreads), 0, st, a);
-  else hipLaunchKernelGGL((act_quant_kernel<VEC, false>), dim3(a.N), dim3(kThreads), 0, st, a);
+int launch_sweep(const Args& a, int q, bool hist, hipStream_t st) {
+  const dim3 grid(a.N), block(kThreads);
+  if (hist) hipLaunchKernelGGL((aq_sweep_kernel<VEC, true, 0>), grid, block, 0, st, a, q);
+  else if (q == 0) hipLaunchKernelGGL((aq_sweep_kernel<VEC, false, 0>), grid, block, 0, st, a, q);
+  else if (q == 1) hipLaunchKernelGGL((aq_sweep_kernel<VEC, false, 1>), grid, block, 0, st, a, q);
+  else hipLaunchKernelGGL((aq_sweep_kernel<VEC, false, 2>), grid, block, 0, st, a, q);
   return (int)hipGetLastError();
+}
+
+// the whole sequence for one batch of rows
+template <int VEC>
+int run(Args a, hipStream_t st) {
+  const bool solver = (a.scheme == LSQ_SCHEME_LS2 || a.scheme == LSQ_SCHEME_LST) && !a.forced;
+  if (a.forced) {
+    hipError_t e = hipMemcpyAsync(a.scales, a.forced, sizeof(float) * (size_t)a.k * a.N, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  for (int q = 0; q < a.k; ++q) {
+    const bool hist = solver && q == 0;
+    a.write_scale = (!a.forced && !(solver && q == 0) && !(a.scheme == LSQ_SCHEME_LST && q == 1)) ? 1 : 0;
+    if (a.flat && q > 0 && !a.write_scale) break;          // dense rows: no planes, nothing left to do
+    if (int e = launch_sweep<VEC>(a, q, hist, st)) return e;
+    if (hist) {
+      hipLaunchKernelGGL((aq_solve_kernel<VEC>), dim3(a.N), dim3(kThreads), 0, st, a);
+      if (int e = (int)hipGetLastError()) return e;
+    }
+  }
+  return LSQ_OK;
 }
 
 }  // namespace
@@ -1143,9 +1276,11 @@ extern "C" int64_t lsq_act_plane_words(const lsq_conv_geom* g) {
   return (int64_t)g->N * g->groups * Gg * (g->H + 2 * g->pad_h) * (g->W + 2 * g->pad_w);
 }
 
+extern "C" int64_t lsq_solver_workspace_bytes(int64_t rows) { return rows > 0 ? rows * kWsRow : -1; }
+
 extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
                              float clamp_alpha, const float* forced, uint64_t* planes, float* scales,
-                             void* stream) {
+                             void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !planes || !scales) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
   if (skip < 1) return LSQ_E_SHAPE;
@@ -1170,21 +1305,28 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   a.scales = scales;
   a.N = g->N;
   a.ternary = scheme == LSQ_SCHEME_LST;
+  a.ws = (unsigned char*)workspace;
   const bool solver = (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && !forced;
-  if (solver && (a.row_elems + skip - 1) / skip >= (1ll << 22)) return LSQ_E_TOO_LONG;
+  if (solver) {
+    if ((a.row_elems + skip - 1) / skip >= (1ll << 22)) return LSQ_E_TOO_LONG;
+    if (!workspace) return LSQ_E_NULL;
+    if ((long long)workspace_bytes < (long long)g->N * kWsRow || ((uintptr_t)workspace % 8)) return LSQ_E_WORKSPACE;
+  }
   const int HW = g->H * g->W;
   const bool al16 = ((uintptr_t)x % 16) == 0, al8 = ((uintptr_t)x % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
-  if (HW % 4 == 0 && al16 && (long long)a.Gt * (HW / 4) >= 512) return launch<4>(a, solver, st);
-  if (HW % 2 == 0 && al8 && (long long)a.Gt * (HW / 2) >= 512) return launch<2>(a, solver, st);
-  return launch<1>(a, solver, st);
+  if (HW % 4 == 0 && al16 && (long long)a.Gt * (HW / 4) >= 512) return run<4>(a, st);
+  if (HW % 2 == 0 && al8 && (long long)a.Gt * (HW / 2) >= 512) return run<2>(a, st);
+  return run<1>(a, st);
 }
 
 extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,
-                              float clamp_alpha, float* v12, int32_t* status, void* stream) {
-  if (!rows || !v12) return LSQ_E_NULL;
+                              float clamp_alpha, float* v12, int32_t* status, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!rows || !v12 || !workspace) return LSQ_E_NULL;
   if (R <= 0 || M <= 0 || skip < 1 || R > 0x7FFFFFFF) return LSQ_E_SHAPE;
   if ((M + skip - 1) / skip >= (1ll << 22)) return LSQ_E_TOO_LONG;
+  if ((long long)workspace_bytes < R * kWsRow || ((uintptr_t)workspace % 8)) return LSQ_E_WORKSPACE;
   Args a = {};
   a.x = rows;
   a.row_elems = M;
@@ -1198,7 +1340,8 @@ extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip,
   a.ternary = ternary ? 1 : 0;
   a.status = status;
   a.scales = v12;
-  return launch<1>(a, true, (hipStream_t)stream);
+  a.ws = (unsigned char*)workspace;
+  return run<1>(a, (hipStream_t)stream);
 }
 
 #ifdef LSQ_PHASE_CLOCKS

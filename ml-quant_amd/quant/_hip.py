@@ -50,9 +50,11 @@ def _declare(lib):
     lib.lsq_weight_plane_words.restype = i64
     lib.lsq_weight_plane_words.argtypes = [gp]
     lib.lsq_act_quant.restype = i32
-    lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp]
+    lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.lsq_solver_workspace_bytes.restype = i64
+    lib.lsq_solver_workspace_bytes.argtypes = [i64]
     lib.lsq_solve_rows.restype = i32
-    lib.lsq_solve_rows.argtypes = [vp, i64, i64, i32, i32, f32, vp, vp, vp]
+    lib.lsq_solve_rows.argtypes = [vp, i64, i64, i32, i32, f32, vp, vp, vp, ctypes.c_size_t, vp]
     lib.lsq_pack_weight.restype = i32
     lib.lsq_pack_weight.argtypes = [vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_xnor_conv2d.restype = i32
@@ -142,13 +144,30 @@ class _Timed:
             _timing.setdefault(self.name, []).append((self.s, self.e, self.nbytes))
 
 
+_ws_cache = {}
+
+
+def solver_workspace(rows: int, device) -> torch.Tensor:
+    """Scratch for the LS2/LST solve (slot records passed from the sweep to the solve kernel); cached per
+    device and grown on demand -- kernels of one stream run in order, so sharing it is safe."""
+    need = lib().lsq_solver_workspace_bytes(rows)
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty((need,), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
 def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, alpha: float,
               planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None) -> None:
     x = _f32c(x)
+    ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) and forced is None else None
     m = geom.C * geom.H * geom.W
     with _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8)):     # x read once + k bit planes written
         check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha), ptr(forced),
-                                  planes.data_ptr(), scales.data_ptr(), stream_ptr()), 'lsq_act_quant')
+                                  planes.data_ptr(), scales.data_ptr(), ptr(ws), 0 if ws is None else ws.numel(),
+                                  stream_ptr()), 'lsq_act_quant')
 
 
 def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0):
@@ -157,8 +176,9 @@ def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0
     r, m = rows.shape
     v12 = torch.empty((2, r), dtype=torch.float32, device=rows.device)
     status = torch.empty((r,), dtype=torch.int32, device=rows.device)
+    ws = solver_workspace(r, rows.device)
     check(lib().lsq_solve_rows(rows.data_ptr(), r, m, skip, int(ternary), float(alpha), v12.data_ptr(),
-                               status.data_ptr(), stream_ptr()), 'lsq_solve_rows')
+                               status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()), 'lsq_solve_rows')
     return v12, status
 
 

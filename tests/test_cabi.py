@@ -29,7 +29,7 @@ def hip():
 
 def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
-        'lsq_abi_version', 'lsq_error_string', 'lsq_act_plane_words', 'lsq_weight_plane_words',
+        'lsq_abi_version', 'lsq_error_string', 'lsq_act_plane_words', 'lsq_weight_plane_words', 'lsq_solver_workspace_bytes',
         'lsq_act_quant', 'lsq_solve_rows', 'lsq_pack_weight', 'lsq_xnor_conv2d', 'lsq_signw_conv2d'])
 
 
@@ -54,8 +54,8 @@ def test_geometry_helpers_and_argument_errors(hip):
     bad = hip.make_geom(2, 20, 12, 12, 50, 5, 5, (1, 1), (0, 0), (1, 1), 3)      # C % groups != 0
     assert lib.lsq_act_plane_words(ctypes.byref(bad)) == -1
     # null pointers / bad schemes are rejected before any launch
-    assert lib.lsq_act_quant(None, ctypes.byref(g), 1, 1, 3, 2.0, None, None, None, None) == -1
-    assert lib.lsq_solve_rows(None, 1, 1, 1, 0, -1.0, None, None, None) == -1
+    assert lib.lsq_act_quant(None, ctypes.byref(g), 1, 1, 3, 2.0, None, None, None, None, 0, None) == -1
+    assert lib.lsq_solve_rows(None, 1, 1, 1, 0, -1.0, None, None, None, 0, None) == -1
     assert lib.lsq_xnor_conv2d(None, 1, None, None, None, 1, None, None, ctypes.byref(g), None, None) == -1
 
 
