@@ -161,7 +161,7 @@ class QuantConv2d(nn.Conv2d):
         y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
         bias = None if self.bias is None else self.bias.detach()
         if self.x_quant == 'fp':
-            _hip.signw_conv2d(self.clamping_fn(x), -1.0, wbits, wscales, bias, geom, y)
+            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y)      # clamp fused into the load
             return y
         xq = self.x_approximate
         k = xq.n_planes

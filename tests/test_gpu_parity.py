@@ -292,6 +292,70 @@ def test_moving_average_eval_mode_uses_fixed_scales():
     assert rel_err(y_gpu, y_cpu) <= TOL
 
 
+@pytest.mark.parametrize('ws', ['ls-1', 'gf-2', 'ls-2'])
+def test_fp_activation_sign_weight_conv_mfma(golden, ws):
+    """x_quant = fp: bf16 hi+lo split on the matrix cores must stay inside 1e-4 of max|y| (a single bf16
+    pass would not: 2^-8 per element)."""
+    g = golden('f5_conv')
+    x = detgen.normal('f5.x', (2, 64, 14, 14), scale=1.2)
+    for stride in (1, 2):
+        key = f'fp_ls-1_s{stride}_a2'
+        clamp = {'kind': 'symmetric', 'alpha': 2}
+        if ws == 'ls-1':
+            conv = make_conv('fp', 'ls-1', 64, 64, 3, clamp, [g[key + '_w_v1']], stride=stride, padding=1, bias=True)
+            ref = g[key + '_y']
+        else:
+            w = detgen.normal('f5.w.64.64.3', (64, 64, 3, 3), scale=(64 * 9) ** -0.5)
+            b = detgen.normal('f5.w.64.64.3.b', (64,), scale=0.1)
+            wsc = P.weight_scales(w, ws)
+            conv = make_conv('fp', ws, 64, 64, 3, clamp, wsc, stride=stride, padding=1, bias=True)
+            ref = P.quant_conv2d(x, w, b, 'fp', ws, wsc, clamp, stride, 1)
+        with torch.no_grad():
+            y = conv(x.to(DEV)).cpu()
+        assert rel_err(y, ref) <= TOL, (ws, stride, rel_err(y, ref))
+    # LeNet geometry (Cin = 20, 5x5, no padding, 50 out channels), identity clamp
+    xl = detgen.normal('f5.xl', (2, 20, 12, 12))
+    conv = make_conv('fp', 'ls-1', 20, 50, 5, None, [g['lenet_fp_ls-1_w_v1']], stride=1)
+    with torch.no_grad():
+        assert rel_err(conv(xl.to(DEV)).cpu(), g['lenet_fp_ls-1_y']) <= TOL
+    # wide / odd channel counts and groups
+    xw = detgen.normal('gpu.fp.xw', (3, 96, 9, 7), scale=2.0)
+    w = detgen.normal('gpu.fp.ww', (160, 48, 3, 3), scale=0.05)
+    b = detgen.normal('gpu.fp.bw', (160,), scale=0.1)
+    wsc = P.weight_scales(w, 'ls-1')
+    from quant.binary.binary_conv import QuantConv2d
+    conv = QuantConv2d('fp', 'ls-1', 96, 160, 3, None, padding=1, groups=2)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(b)
+        conv.w_approximate.v1.copy_(wsc[0])
+    conv.eval().to(DEV)
+    with torch.no_grad():
+        y = conv(xw.to(DEV)).cpu()
+    assert rel_err(y, P.quant_conv2d(xw, w, b, 'fp', 'ls-1', wsc, None, 1, 1, 1, 2)) <= TOL
+
+
+def test_config0_lenet_and_fp_act_resnet_on_gpu(golden):
+    """BASELINE configs[0] (LeNet, ls-1 weights, fp activations) and configs[3] (ResNet-18 ls-1w / fp-a)
+    end to end on the GPU against the reference's outputs."""
+    from quant.binary.binary_conv import QuantConv2d
+    from quant.models.lenet import QLeNet5
+    g7, g6 = golden('f7_lenet'), golden('f6_models')
+    model = QLeNet5(loss_fn=None, **g7.json('mnist_ls1w_fpa_arch'))
+    detgen.fill_module(model, seed=3)
+    with torch.no_grad():
+        model.conv2.w_approximate.v1.copy_(P.weight_scales(model.conv2.weight, 'ls-1')[0])
+    model.eval().to(DEV)
+    with torch.no_grad():
+        y = model(detgen.normal('mnist_ls1w_fpa.x', (64, 1, 28, 28)).to(DEV)).cpu()
+    assert torch.allclose(y, g7['mnist_ls1w_fpa_logp'], atol=2e-4, rtol=0)
+    tag = 'imagenet_ls1w_fpa'
+    model = _build_model(g6.json(tag + '_arch'), seed=1).to(DEV)
+    with torch.no_grad():
+        y = model(detgen.normal(tag + '.x', (2, 3, 64, 64)).to(DEV)).cpu()
+    assert rel_err(y, g6[tag + '_logits']) <= 1e-3, rel_err(y, g6[tag + '_logits'])
+
+
 # ------------------------------------------------------------------------------------------------
 def _build_model(arch, seed):
     from quant.binary.binary_conv import QuantConv2d
