@@ -77,6 +77,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--cpu-sample', type=int, default=48, help='images for the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--act', default='ls-2', choices=['ls-1', 'ls-2', 'ls-T', 'gf-2', 'fp'],
+                    help='activation scheme (default: the headline ls-2 config)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -90,7 +92,7 @@ def main():
     device = torch.device('cuda', local)
 
     from quant import _hip
-    arch = imagenet_arch()
+    arch = imagenet_arch(args.act, 3 if args.act == 'ls-2' else 2)
     model = build_model(arch, device)
     g = torch.Generator(device='cpu').manual_seed(rank)
     x = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)       # resident in HBM before timing
@@ -122,12 +124,13 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'images/sec ResNet-18 LS-1w/LS-2a 224x224 eval forward',
+            'metric': 'images/sec ResNet-18 LS-1w/LS-2a 224x224 eval forward' if args.act == 'ls-2' else
+                      f'images/sec ResNet-18 ls-1w/{args.act}-a 224x224 eval forward',
             'value': world * args.batch * args.steps / elapsed, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u64 popcount + f32', 'data': 'synthetic',
-            'config': {'workload': 'ResNet-18 ImageNet ls-1 weight / ls-2 activation (configs[2]), '
+            'config': {'workload': f'ResNet-18 ImageNet ls-1 weight / {args.act} activation, '
                                    f'synthetic 3x224x224, batch {args.batch} per GPU, random-init weights',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world} (batch-sharded replicas, '
                                                                           'RCCL all-gather of logits)'},
@@ -135,14 +138,25 @@ def main():
         if not args.no_roofline:
             stats = _hip.drain_timing()
             name = max(stats, key=lambda k: stats[k][1])
-            launches, ms, nbytes = stats[name]
-            achieved = nbytes / (ms * 1e-3) / 1e9
-            out['roofline'] = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                               'frac': achieved / 8000.0, 'traffic': None, 'launches': launches,
-                               'avg_launch_us': 1e3 * ms / launches,
-                               'kernels': {k: {'launches': v[0], 'ms_per_step': v[1] / args.steps,
-                                               'algorithmic_GBps': v[2] / (v[1] * 1e-3) / 1e9}
-                                           for k, v in stats.items()}}
+            launches, ms, nbytes, ops = stats[name]
+            kern = {}
+            for k, v in stats.items():
+                kern[k] = {'launches': v[0], 'ms_per_step': v[1] / args.steps,
+                           'algorithmic_GBps': v[2] / (v[1] * 1e-3) / 1e9}
+                if k == 'lsq_xnor_conv2d':      # VALU popcount: 2 ops / 32 MACs; v_bcnt_u32_b32 measured at half rate
+                    kern[k]['T_binary_MAC_per_s'] = v[3] / (v[1] * 1e-3) / 1e12
+                    kern[k]['frac_of_valu_popcount_peak_1258T'] = kern[k]['T_binary_MAC_per_s'] / 1258.0
+                if k == 'lsq_signw_conv2d':
+                    kern[k]['TFLOPs_bf16'] = v[3] / (v[1] * 1e-3) / 1e12
+            if name == 'lsq_signw_conv2d':
+                achieved = ops / (ms * 1e-3) / 1e12
+                out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': 2500.0,
+                                   'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': None}
+            else:
+                achieved = nbytes / (ms * 1e-3) / 1e9
+                out['roofline'] = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': 8000.0,
+                                   'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': None}
+            out['roofline'].update(launches=launches, avg_launch_us=1e3 * ms / launches, kernels=kern)
         if args.cpu_sample > 0 and world == 1:
             out['cpu_baseline'] = cpu_baseline(arch, model, args.cpu_sample)
         print(json.dumps(out))

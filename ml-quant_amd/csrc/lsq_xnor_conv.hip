@@ -33,6 +33,7 @@ struct ConvArgs {
   int N, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
   int Gg, Gt, Hp, Wp, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
   int accumulate;
+  int tap_xoff[64];                    // (kh*dil_h)*Wp + kw*dil_w per tap
 };
 
 template <int KX, int OT>
@@ -62,26 +63,49 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
       a.xplanes + ((long long)n * a.Gt + (long long)grp * a.Gg) * HpWp + (long long)(ho * a.sh) * a.Wp + wo * a.sw;
   const unsigned long long* __restrict__ wbase = a.wbits + o_pad0;
 
+  // Loop over (channel word j, tap).  Everything address-like is a 32-bit word offset that advances by
+  // a loop-invariant stride (the first version spent as many SALU instructions on 64-bit index math and
+  // integer divisions as VALU instructions on popcounts); tap offsets come precomputed in the kernel
+  // arguments.  The activation words of the next step are requested before this step's popcounts.
+  const int taps = a.KH * a.KW;
+  const int plane_stride = (int)a.xplane_words;
+  const int wstep = a.Gg * a.opad_total;            // weight words between consecutive taps
+  int xbase = 0;                                     // j * Hp * Wp
+  unsigned long long xn[KX];
+#pragma unroll
+  for (int p = 0; p < KX; ++p) xn[p] = xp[p * plane_stride + a.tap_xoff[0]];
   for (int j = 0; j < a.Gg; ++j) {
-    for (int kh = 0; kh < a.KH; ++kh) {
-      for (int kw = 0; kw < a.KW; ++kw) {
-        const long long off = (long long)j * HpWp + (long long)(kh * a.dh) * a.Wp + kw * a.dw;
-        unsigned long long xa[KX];
+    const unsigned long long* __restrict__ wp = wbase + j * a.opad_total;
+    for (int tp = 0; tp < taps; ++tp) {
+      unsigned long long xa[KX];
 #pragma unroll
-        for (int p = 0; p < KX; ++p) xa[p] = xp[(long long)p * a.xplane_words + off];
-        const unsigned long long* __restrict__ wp = wbase + ((long long)(kh * a.KW + kw) * a.Gg + j) * a.opad_total;
+      for (int p = 0; p < KX; ++p) xa[p] = xn[p];
+      {
+        const bool last_tap = tp + 1 == taps;
+        const int nb = last_tap ? xbase + (int)HpWp : xbase;
+        const int noff = nb + a.tap_xoff[last_tap ? 0 : tp + 1];
+        if (!(last_tap && j + 1 == a.Gg)) {
 #pragma unroll
-        for (int o = 0; o < OT; ++o) {
-          const unsigned long long wv = wp[o];
-#pragma unroll
-          for (int p = 0; p < KX; ++p) acc[p][o] += __popcll(xa[p] ^ wv);
+          for (int p = 0; p < KX; ++p) xn[p] = xp[p * plane_stride + noff];
         }
       }
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+        const unsigned long long wv = wp[o];           // wave-uniform: scalar load, SGPR operand
+#pragma unroll
+        for (int p = 0; p < KX; ++p) {
+          const unsigned lo = (unsigned)xa[p] ^ (unsigned)wv, hi = (unsigned)(xa[p] >> 32) ^ (unsigned)(wv >> 32);
+          // v_bcnt_u32_b32 accumulates: acc = popcount(x) + acc, one VALU op per 32 bits
+          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[p][o]) : "v"(lo));
+          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[p][o]) : "v"(hi));
+        }
+      }
+      wp += wstep;
     }
+    xbase += (int)HpWp;
   }
 
   // border correction: out-of-image taps were computed against zero words
-  const int taps = a.KH * a.KW;
   int corr[OT];
 #pragma unroll
   for (int o = 0; o < OT; ++o) corr[o] = 0;
@@ -152,6 +176,9 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
   a.opad_total = g->groups * a.og_pad;
   a.tiles_per_group = a.og_pad / 16;
   a.xplane_words = lsq_act_plane_words(g);
+  if (g->KH * g->KW > 64 || a.xplane_words * kx >= (1ll << 31)) return LSQ_E_UNSUPPORTED;
+  for (int kh = 0; kh < g->KH; ++kh)
+    for (int kw = 0; kw < g->KW; ++kw) a.tap_xoff[kh * g->KW + kw] = kh * g->dil_h * a.Wp + kw * g->dil_w;
   a.bias = bias;
   a.y = y;
   const long long wplane_words = lsq_weight_plane_words(g);

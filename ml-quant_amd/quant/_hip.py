@@ -120,17 +120,19 @@ def enable_timing(on: bool = True) -> None:
 
 
 def drain_timing():
-    """{kernel: (launches, total_ms, total_algorithmic_bytes)}; call after torch.cuda.synchronize()."""
+    """{kernel: (launches, total_ms, total_algorithmic_bytes, total_ops)}; call after torch.cuda.synchronize().
+    ops = binary MACs (xnor conv) or bf16 FLOPs (sign-weight conv), 0 for the quantizer."""
     out = {}
     for name, recs in (_timing or {}).items():
-        out[name] = (len(recs), sum(s.elapsed_time(e) for s, e, _ in recs), sum(b for _, _, b in recs))
+        out[name] = (len(recs), sum(s.elapsed_time(e) for s, e, _ in recs), sum(b[0] for _, _, b in recs),
+                     sum(b[1] for _, _, b in recs))
         recs.clear()
     return out
 
 
 class _Timed:
-    def __init__(self, name, nbytes):
-        self.name, self.nbytes = name, nbytes
+    def __init__(self, name, nbytes, ops=0):
+        self.name, self.nbytes = name, (nbytes, ops)
 
     def __enter__(self):
         if _timing is not None:
@@ -208,7 +210,8 @@ def out_hw(geom: ConvGeom):
 def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: torch.Tensor, wsum: torch.Tensor,
                 wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
     m = geom.C * geom.H * geom.W
-    with _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel()):   # bit planes read + fp32 output written
+    macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
+    with _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs):   # planes read + fp32 output written
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(),
                                     stream_ptr()), 'lsq_xnor_conv2d')
@@ -217,5 +220,8 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
 def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,
                  bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
     x = _f32c(x)
-    check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), wbits.data_ptr(), wscales.shape[0], wscales.data_ptr(),
-                                 ptr(bias), ctypes.byref(geom), y.data_ptr(), stream_ptr()), 'lsq_signw_conv2d')
+    flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
+    with _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel(), flops):     # fp32 input read + fp32 output written
+        check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), wbits.data_ptr(), wscales.shape[0],
+                                     wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(), stream_ptr()),
+              'lsq_signw_conv2d')

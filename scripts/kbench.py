@@ -46,7 +46,7 @@ def main():
     dev = 'cuda:0'
     sch = {'ls-1': (1, 1), 'ls-2': (2, 2), 'ls-T': (3, 2), 'gf-2': (4, 2)}[args.scheme]
     n = args.batch
-    tot_q = tot_c = 0.0
+    tot_q = tot_c = tot_f = 0.0
     for c, h, o, stride, count in SHAPES:
         x = torch.randn(n, c, h, h, device=dev)
         w = torch.randn(o, c, 3, 3, device=dev)
@@ -61,15 +61,18 @@ def main():
         bias = torch.zeros(o, device=dev)
         tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales), args.iters)
         tc = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), args.iters)
+        tf = timeit(lambda: _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y), args.iters)
         m = c * h * h
         qbytes = n * (4 * m + k * m // 8)
         macs = n * o * ho * wo * c * 9 * k
         print(f'C={c:4d} H={h:3d} O={o:4d} s={stride}  act_quant {tq:8.1f} us  {qbytes / tq / 1e3:7.1f} GB/s alg | '
-              f'xnor_conv {tc:8.1f} us  {macs / tc / 1e6:9.1f} T binary-MAC/s   (x{count})')
+              f'xnor_conv {tc:8.1f} us  {macs / tc / 1e6:9.1f} T binary-MAC/s | '
+              f'signw(mfma) {tf:8.1f} us {2 * 2 * macs / k / tf / 1e6:7.1f} TFLOP/s bf16 (2 passes)   (x{count})')
+        tot_f += tf * count
         tot_q += tq * count
         tot_c += tc * count
     print(f'per forward (16 layers, batch {n}): act_quant {tot_q / 1e3:.2f} ms, xnor_conv {tot_c / 1e3:.2f} ms '
-          f'=> path-only {n / ((tot_q + tot_c) * 1e-6):.0f} images/s')
+          f'=> path-only {n / ((tot_q + tot_c) * 1e-6):.0f} images/s;  fp-act signw conv {tot_f / 1e3:.2f} ms')
 
 
 if __name__ == '__main__':
