@@ -35,15 +35,16 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / kWave;
-constexpr int L1_SHIFT = 19, L1_BINS = 4096;   // key bits [30:19]
-constexpr int L2_SHIFT = 9, L2_BINS = 1024;    // key bits [18:9]
-constexpr int L3_BINS = 512;                   // key bits [8:0]
+constexpr int L1_SHIFT = 18, L1_BINS = 8192;   // key bits [30:18]: 32 bins per binade
+constexpr int kBinsPerThread = L1_BINS / kThreads;
+constexpr int L2_SHIFT = 8, L2_BINS = 1024;    // block path: key bits [17:8]
+constexpr int L3_BINS = 256;                   // block path: key bits [7:0]
+constexpr int kKeysPerLane = L3_BINS / kWave;
 constexpr int kSlotCap = 256;                  // flagged level-1 bins held as slot records
 constexpr int kSubSlots = 126;                 // slots gathered per sub-round (role table bytes)
 constexpr int kSeg3 = 8;                       // level-2 bins refined per level-3 pass
-constexpr int kListCap = 14336;                // gathered keys held in LDS (own region)
-constexpr int kListExt = kListCap + 2 * L1_BINS;   // ... plus the retired level-1 histogram
-constexpr int kWaveSub = 256, kWaveShift = 11; // wave-level refinement: key bits [18:11]
+constexpr int kListExt = 22528;                // gathered keys held in LDS (88 KB)
+constexpr int kWaveSub = 256, kWaveShift = 10; // wave-level refinement: key bits [17:10]
 constexpr unsigned kNoKey = 0xFFFFFFFFu;
 constexpr unsigned long long kOne = 1ull << 42;          // count field of a histogram word
 constexpr unsigned long long kLowMask = kOne - 1;
@@ -97,16 +98,21 @@ struct BlockHists {
 };
 
 struct SolverLds {
-  // `list` and `hist1` are contiguous on purpose: once the level-1 histogram has been read into
-  // registers its 32 KB extend the gathered-key list to kListExt keys.
-  unsigned list[kListCap];
-  unsigned long long hist1[L1_BINS];
+  // gathered keys of the flagged bins; rows with more than kSlotCap flagged bins never use the list and
+  // re-scan the level-1 histogram instead, which then lives in the same bytes
+  union {
+    unsigned list[kListExt];
+    struct {
+      unsigned long long hist1[L1_BINS];
+      unsigned short nzlist1[L1_BINS];
+    } big;
+  } k;
   union {
     BlockHists blk;                                    // block-level (slow) refinement
     unsigned long long whist[kWaves][kWaveSub];        // wave-level (fast) refinement
   } u;
   unsigned wkeys[kWaves][kWave];
-  unsigned short nzlist[L1_BINS];
+  unsigned short nzlist[L2_BINS];                      // block path, level 2
   unsigned short role[L1_BINS];                        // low byte: 1 + gather slot; high byte: 1 + successor slot
   Slot1 slot[kSlotCap];
   unsigned fill[kSubSlots];
@@ -120,6 +126,8 @@ struct SolverLds {
   Best wbest[kWaves];
   // scalars
   unsigned n_sub, n_cand, n_slow, blk_succ;
+  unsigned dbg_slow, dbg_gathered, dbg_rowpass;   // diagnostics written back to the row header
+  unsigned rg_lo[4], rg_len[4], rg_first[4], rg_succbin[4], rg_last[4], n_rg;   // runs of consecutive flagged bins
   unsigned minkey;
   double total;
   float sv[LSQ_MAX_PLANES];
@@ -552,7 +560,8 @@ __device__ __forceinline__ void for_each_row_key(const Args& a, const float* __r
 // level 1: scan the 4096-bin histogram (4 bins per thread), flag bins that may hold a candidate, and
 // write a slot record for the flagged bins with ordinal in [round0, round0 + kSlotCap)
 template <class L>
-__device__ __forceinline__ unsigned l1_scan(L* lds, unsigned n, unsigned round0) {
+__device__ __forceinline__ unsigned l1_scan(L* lds, const unsigned long long* hist1, unsigned short* nzl, unsigned n,
+                                        unsigned round0) {
   const float* xrow = nullptr;
   const Args& a = lds->args;
   const unsigned* list = nullptr;
@@ -560,14 +569,14 @@ __device__ __forceinline__ unsigned l1_scan(L* lds, unsigned n, unsigned round0)
   const bool ternary = a.ternary != 0;
   double total = 0.0;
   (void)a; (void)xrow; (void)n; (void)list; (void)tid; (void)lane; (void)wid; (void)ternary;
-  unsigned cnt[4];
-  double sum[4];
+  unsigned cnt[kBinsPerThread];
+  double sum[kBinsPerThread];
   unsigned my_nz = 0, my_cnt = 0;
   double my_sum = 0.0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned b = 4u * tid + u;
-    const unsigned long long h = lds->hist1[b];
+  for (int u = 0; u < kBinsPerThread; ++u) {
+    const unsigned b = (unsigned)kBinsPerThread * tid + u;
+    const unsigned long long h = hist1[b];
     cnt[u] = (unsigned)(h >> 42);
     sum[u] = cnt[u] ? bin_sum_exact(b << L1_SHIFT, cnt[u], h & kLowMask) : 0.0;
     my_nz += cnt[u] ? 1u : 0u;
@@ -580,27 +589,27 @@ __device__ __forceinline__ unsigned l1_scan(L* lds, unsigned n, unsigned round0)
   {
     unsigned z = enz;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (cnt[u]) lds->nzlist[z++] = (unsigned short)(4u * tid + u);
+    for (int u = 0; u < kBinsPerThread; ++u)
+      if (cnt[u]) nzl[z++] = (unsigned short)((unsigned)kBinsPerThread * tid + u);
   }
   __syncthreads();
   unsigned my_flags = 0;
-  bool flag[4];
-  unsigned short nxt[4];
+  bool flag[kBinsPerThread];
+  unsigned short nxt[kBinsPerThread];
   {
     unsigned z = enz, c = ecnt;
     double s = esum;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kBinsPerThread; ++u) {
       flag[u] = false;
       nxt[u] = 0xFFFFu;
       if (cnt[u]) {
-        const unsigned b = 4u * tid + u;
+        const unsigned b = (unsigned)kBinsPerThread * tid + u;
         const double vlo = (double)key_value(b << L1_SHIFT);
         const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
         double next_hi = vhi;
         if (z + 1 < tnz) {
-          nxt[u] = lds->nzlist[z + 1];
+          nxt[u] = nzl[z + 1];
           next_hi = (double)key_value(((unsigned)nxt[u] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
         }
         flag[u] = n >= 3u && may_hold_candidate(c, cnt[u], s, sum[u], vlo, vhi, next_hi, n, total, ternary);
@@ -618,11 +627,11 @@ __device__ __forceinline__ unsigned l1_scan(L* lds, unsigned n, unsigned round0)
     unsigned ord = eflag, c = ecnt;
     double s = esum;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kBinsPerThread; ++u) {
       if (flag[u]) {
         if (ord >= round0 && ord < round0 + (unsigned)kSlotCap) {
           Slot1 sl;
-          sl.bin = (unsigned short)(4u * tid + u);
+          sl.bin = (unsigned short)((unsigned)kBinsPerThread * tid + u);
           sl.next_bin = nxt[u];
           sl.cnt = cnt[u];
           sl.r0 = c;
@@ -651,7 +660,7 @@ __device__ __forceinline__ unsigned l1_scan(L* lds, unsigned n, unsigned round0)
 __device__ __noinline__ Best resolve_slot_block(SolverLds* lds, const float* __restrict__ xrow, unsigned n, unsigned si,
                                                bool from_row, Best best) {
   const Args& a = lds->args;
-  unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
+  unsigned* const list = lds->k.list;          // kListExt keys (runs on into hist1)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool ternary = a.ternary != 0;
   const double total = lds->total;
@@ -743,19 +752,19 @@ __device__ __noinline__ Best resolve_slot_block(SolverLds* lds, const float* __r
     if ((unsigned)wid < nseg) {
       const Seg3 g = lds->seg[wid];
       const unsigned succ_s = lds->succ3[wid];
-      unsigned kc[8];
+      unsigned kc[kKeysPerLane];
       unsigned lane_cnt = 0;
       double lane_sum = 0.0;
       unsigned first_key = kNoKey;
 #pragma unroll
-      for (int u = 7; u >= 0; --u) {
-        kc[u] = lds->u.blk.hist3[wid][lane * 8 + u];
-        if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+      for (int u = kKeysPerLane - 1; u >= 0; --u) {
+        kc[u] = lds->u.blk.hist3[wid][lane * kKeysPerLane + u];
+        if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kKeysPerLane; ++u) {
         lane_cnt += kc[u];
-        lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u));
+        lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u));
       }
       const unsigned ic = wave_incl_scan(lane_cnt);
       const double is = wave_incl_scan(lane_sum);
@@ -772,17 +781,17 @@ __device__ __noinline__ Best resolve_slot_block(SolverLds* lds, const float* __r
       }
       unsigned run_r0 = g.r0 + (ic - lane_cnt);
       double run_p0 = g.p0 + (is - lane_sum);
-      unsigned nextk[8];
+      unsigned nextk[kKeysPerLane];
       unsigned cur = after != kNoKey ? after : succ_s;
 #pragma unroll
-      for (int u = 7; u >= 0; --u) {
+      for (int u = kKeysPerLane - 1; u >= 0; --u) {
         nextk[u] = cur;
-        if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+        if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u);
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kKeysPerLane; ++u) {
         if (kc[u]) {
-          const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * 8 + u);
+          const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u);
           const double v = (double)key_value(key);
           const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
           if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, total, ternary)) {
@@ -814,7 +823,7 @@ struct WaveOut {
 __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n, unsigned si, Best best) {
   const float* xrow = nullptr;
   const Args& a = lds->args;
-  unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
+  unsigned* const list = lds->k.list;          // kListExt keys (runs on into hist1)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool ternary = a.ternary != 0;
   const double total = lds->total;
@@ -998,35 +1007,118 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
 template <int VEC>
 __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restrict__ xrow, unsigned n, unsigned sb) {
   const Args a = lds->args;
-  unsigned* const list = lds->list;
+  unsigned* const list = lds->k.list;
+  // The flagged bins of a sub-round usually form <= 4 runs of consecutive bins: membership is then a
+  // few VALU compares against SGPR constants instead of an LDS table lookup per key (the gather is
+  // bound by LDS instruction issue, not by the loads), and fill[] starts at the segment base so the
+  // returning atomic yields the absolute list position.
+  const unsigned n_rg = (unsigned)__builtin_amdgcn_readfirstlane((int)lds->n_rg);
+  unsigned lo[4], len[4], first[4], succbin[4], last[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    lo[r] = (unsigned)__builtin_amdgcn_readfirstlane((int)lds->rg_lo[r]);
+    len[r] = (unsigned)__builtin_amdgcn_readfirstlane((int)lds->rg_len[r]);
+    first[r] = (unsigned)__builtin_amdgcn_readfirstlane((int)lds->rg_first[r]);
+    succbin[r] = (unsigned)__builtin_amdgcn_readfirstlane((int)lds->rg_succbin[r]);
+    last[r] = (unsigned)__builtin_amdgcn_readfirstlane((int)lds->rg_last[r]);
+  }
   auto take = [&](unsigned key) {
-    const unsigned r = lds->role[key >> L1_SHIFT];
-    const unsigned gs = r & 0xFFu, ss = r >> 8;
-    if (gs) {
-      const Slot1* sl = &lds->slot[sb + gs - 1u];
-      list[sl->base + atomicAdd(&lds->fill[gs - 1u], 1u)] = key;
+    const unsigned bin = key >> L1_SHIFT;
+    if (n_rg) {
+      unsigned gs = kNoKey;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned d = bin - lo[r];
+        if (d < len[r]) gs = first[r] + d;
+      }
+      if (gs != kNoKey) list[atomicAdd(&lds->fill[gs], 1u)] = key;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (bin == succbin[r]) {
+          unsigned* sp = &lds->slot[sb + last[r]].succ;
+          if (key < *sp) atomicMin(sp, key);
+        }
+      }
+      return;
     }
+    const unsigned r = lds->role[bin];
+    const unsigned gs = r & 0xFFu, ss = r >> 8;
+    if (gs) list[atomicAdd(&lds->fill[gs - 1u], 1u)] = key;
     if (ss) {
       unsigned* sp = &lds->slot[sb + ss - 1u].succ;
       if (key < *sp) atomicMin(sp, key);
     }
   };
-  if (a.flat) {
+  // The gather needs no bit packing, so it does not use the lane = pixel sweep: a flat, fully coalesced
+  // float4 walk keeps all 1024 lanes busy whatever the layer's H*W is.  flat = 4*i, so flat % 3 = i % 3
+  // and for skip = 3 exactly one of the first three elements is sub-sampled (plus the fourth when
+  // i % 3 == 0).  Two phases per batch of U loads keep the returning LDS atomics in flight together.
+  const long long M = a.row_elems;
+  const bool vec_ok = a.skip == 3 && (M % 4) == 0 && (((uintptr_t)xrow) % 16) == 0 && n_rg != 0u;
+  if (!vec_ok) {
     for_each_row_key(a, xrow, n, take);
-  } else {
-    const unsigned skip = (unsigned)a.skip;
-    sweep_row<VEC, true>(
-        a, xrow, []() {},
-        [&](int, const float (&x)[VEC], unsigned rem) {
-          emit_subsample<VEC>(x, rem, skip, [&](float xs) { take(abs_key(xs)); });
-        },
-        [](int, int) {});
+    return;
+  }
+  const float4* __restrict__ row4 = reinterpret_cast<const float4*>(xrow);
+  const unsigned nvec = (unsigned)(M / 4);
+  constexpr int U = 8;
+  unsigned rem0 = threadIdx.x % 3u;                  // (i % 3) for i = tid; advances by 1024 % 3 = 1 per step
+  for (unsigned i0 = threadIdx.x; i0 < nvec; i0 += kThreads * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = row4[min(i0 + (unsigned)u * kThreads, nvec - 1u)];
+    unsigned keys[U][2], pos[U][2];
+    bool tk[U][2];
+    unsigned rem = rem0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = i0 + (unsigned)u * kThreads < nvec;
+      float xs[2];
+      bool has[2];
+      xs[0] = rem == 0u ? v[u].x : (rem == 1u ? v[u].z : v[u].y);
+      has[0] = live;
+      xs[1] = v[u].w;
+      has[1] = live && rem == 0u;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned key = abs_key(clamp_sym(xs[e], a.alpha));
+        const unsigned bin = key >> L1_SHIFT;
+        unsigned gs = kNoKey;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned d = bin - lo[r];
+          if (d < len[r]) gs = first[r] + d;
+        }
+        keys[u][e] = key;
+        tk[u][e] = has[e] && gs != kNoKey;
+        pos[u][e] = 0u;
+        if (tk[u][e]) pos[u][e] = atomicAdd(&lds->fill[gs], 1u);
+        if (has[e]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (bin == succbin[r]) {
+              unsigned* sp = &lds->slot[sb + last[r]].succ;
+              if (key < *sp) atomicMin(sp, key);
+            }
+          }
+        }
+      }
+      rem = rem == 2u ? 0u : rem + 1u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (tk[u][e]) list[pos[u][e]] = keys[u][e];
+    rem0 = (rem0 + (unsigned)(U % 3)) % 3u;
   }
 }
 
 // The solve proper.  On entry the slot records of the flagged level-1 bins are in lds->slot (or, for
 // tflag > kSlotCap, the level-1 histogram is back in lds->hist1) and lds->total is set.
-__device__ __noinline__ unsigned l1_rescan(SolverLds* lds, unsigned n, unsigned round0) { return l1_scan(lds, n, round0); }
+__device__ __noinline__ unsigned l1_rescan(SolverLds* lds, unsigned n, unsigned round0) {
+  return l1_scan(lds, lds->k.big.hist1, lds->k.big.nzlist1, n, round0);
+}
 
 template <int VEC>
 __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restrict__ xrow, unsigned n, unsigned minkey,
@@ -1038,7 +1130,7 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
   best.cost = INFINITY;
   best.order = kNoKey;
   best.value = 0.f;
-  unsigned* const list = lds->list;          // kListExt keys (runs on into hist1)
+  unsigned* const list = lds->k.list;          // kListExt keys (runs on into hist1)
   (void)list;
   LSQ_MARK(2);
   LSQ_MARK(3);
@@ -1073,24 +1165,71 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       const unsigned sb = lds->sub_begin[sr], se = lds->sub_begin[sr + 1];
       __syncthreads();
       if (se - sb == 1u && lds->slot[sb].cnt > (unsigned)kListExt) {
+        if (tid == 0) lds->dbg_rowpass += 1;
         best = resolve_slot_block(lds, xrow, n, sb, true, best);              // one huge bin: histogram straight from the row
         continue;
       }
-      for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->role)[i] = 0u;
-      if (tid < kSubSlots) lds->fill[tid] = 0u;
-      if (tid == 0) lds->n_slow = 0;
-      __syncthreads();
-      if ((unsigned)tid < se - sb) {
-        const Slot1 sl = lds->slot[sb + tid];
-        atomicOr((unsigned*)&lds->role[sl.bin & ~1u], (unsigned)(tid + 1) << (16 * (sl.bin & 1u)));
-        if (sl.next_bin != 0xFFFFu)
-          atomicOr((unsigned*)&lds->role[sl.next_bin & ~1u], (unsigned)(tid + 1) << (8 + 16 * (sl.next_bin & 1u)));
+      if (tid == 0) {
+        lds->n_slow = 0;
+        // runs of consecutive flagged bins (slots are in ascending bin order)
+        unsigned nr = 0;
+        bool fits = true;
+        for (unsigned q = sb; q < se && fits; ++q) {
+          const unsigned b = lds->slot[q].bin;
+          if (nr && b == lds->rg_lo[nr - 1] + lds->rg_len[nr - 1]) {
+            lds->rg_len[nr - 1] += 1;
+          } else if (nr == 4) {
+            fits = false;
+          } else {
+            lds->rg_lo[nr] = b;
+            lds->rg_len[nr] = 1;
+            lds->rg_first[nr] = q - sb;
+            ++nr;
+          }
+        }
+        for (unsigned r = 0; r < 4; ++r) {
+          if (r >= nr) {
+            lds->rg_lo[r] = 0; lds->rg_len[r] = 0; lds->rg_first[r] = 0; lds->rg_succbin[r] = kNoKey; lds->rg_last[r] = 0;
+          } else {
+            const unsigned lastq = lds->rg_first[r] + lds->rg_len[r] - 1;
+            lds->rg_last[r] = lastq;
+            const unsigned nb = lds->slot[sb + lastq].next_bin;
+            lds->rg_succbin[r] = nb == 0xFFFFu ? kNoKey : nb;
+          }
+        }
+        lds->n_rg = fits ? nr : 0u;
       }
+      if ((unsigned)tid < se - sb) lds->fill[tid] = lds->slot[sb + tid].base;     // absolute list positions
       __syncthreads();
+      if (lds->n_rg == 0u) {            // > 4 runs: membership through the role table instead
+        for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->role)[i] = 0u;
+        __syncthreads();
+        if ((unsigned)tid < se - sb) {
+          const Slot1 sl = lds->slot[sb + tid];
+          atomicOr((unsigned*)&lds->role[sl.bin & ~1u], (unsigned)(tid + 1) << (16 * (sl.bin & 1u)));
+          if (sl.next_bin != 0xFFFFu)
+            atomicOr((unsigned*)&lds->role[sl.next_bin & ~1u], (unsigned)(tid + 1) << (8 + 16 * (sl.next_bin & 1u)));
+        }
+        __syncthreads();
+      }
       // gather pass: every key of a flagged bin goes to its slot's segment of the LDS list; keys of
       // the bin right above a flagged bin update that slot's successor key
+      LSQ_MARK(13);
       gather_keys<VEC>(lds, xrow, n, sb);
       __syncthreads();
+      if (lds->n_rg) {
+        // inside a run the successor of a bin's largest key is the smallest key of the next slot's segment
+        for (unsigned si = sb + (unsigned)wid; si + 1 < se; si += kWaves) {
+          const Slot1 nx = lds->slot[si + 1];
+          if (lds->slot[si].next_bin == nx.bin) {
+            unsigned mn = kNoKey;
+            for (unsigned i = lane; i < nx.cnt; i += kWave) mn = min(mn, list[nx.base + i]);
+            mn = wave_min(mn);
+            if (lane == 0) lds->slot[si].succ = mn;
+          }
+        }
+        __syncthreads();
+      }
       LSQ_MARK(4);
       for (unsigned si = sb + (unsigned)wid; si < se; si += kWaves) {
         const WaveOut wo = resolve_slot_wave(lds, n, si, best);
@@ -1102,6 +1241,10 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       __syncthreads();
       LSQ_MARK(5);
       const unsigned n_slow = lds->n_slow;
+      if (tid == 0) {
+        lds->dbg_slow += n_slow;
+        for (unsigned q = sb; q < se; ++q) lds->dbg_gathered += lds->slot[q].cnt;
+      }
       for (unsigned q = 0; q < n_slow; ++q) best = resolve_slot_block(lds, xrow, n, lds->slow[q], false, best);
     }
   }
@@ -1175,7 +1318,7 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
     __syncthreads();
     unsigned minkey = kNoKey;
     for (int w = 0; w < kWaves; ++w) minkey = min(minkey, lds->wa[w]);
-    const unsigned tflag = l1_scan(lds, n_sub, 0);
+    const unsigned tflag = l1_scan(lds, lds->hist1, lds->nzlist, n_sub, 0);
     unsigned char* wrow = a.ws + (long long)row * kWsRow;
     if (tid == 0) {
       RowHeader h;
@@ -1210,15 +1353,17 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
   const int tid = threadIdx.x;
   const float* xrow = a.x + (long long)row * a.row_elems;
   const unsigned char* wrow = a.ws + (long long)row * kWsRow;
+  LSQ_MARK(10);
   const RowHeader h = *reinterpret_cast<const RowHeader*>(wrow);
   if (tid == 0) {
     lds->args = a;
     lds->total = h.total;
     lds->n_cand = 0;
+    lds->dbg_slow = lds->dbg_gathered = lds->dbg_rowpass = 0;
   }
   if (h.tflag > (unsigned)kSlotCap) {
     const unsigned long long* hs = reinterpret_cast<const unsigned long long*>(wrow + kWsHist);
-    for (int i = tid; i < L1_BINS; i += kThreads) lds->hist1[i] = hs[i];
+    for (int i = tid; i < L1_BINS; i += kThreads) lds->k.big.hist1[i] = hs[i];
   } else {
     const unsigned words = h.tflag * (unsigned)(sizeof(Slot1) / 4);
     const unsigned* src = reinterpret_cast<const unsigned*>(wrow + kWsSlots);
@@ -1226,11 +1371,17 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
     for (unsigned i = tid; i < words; i += kThreads) dst[i] = src[i];
   }
   __syncthreads();
+  LSQ_MARK(11);
   const float v1 = solve_v1<VEC>(lds, xrow, h.n, h.minkey, h.tflag);
+  LSQ_MARK(12);
   if (tid == 0) {
     a.scales[row] = v1;
     if (a.ternary) a.scales[(long long)a.N + row] = v1;
     if (a.status) a.status[row] = (int)lds->n_cand;
+    // diagnostics for tooling (scripts/solve_stats.py): slow slots, gathered keys, row-pass slots
+    RowHeader* hw = reinterpret_cast<RowHeader*>(a.ws + (long long)row * kWsRow);
+    hw->pad = lds->dbg_slow | (lds->dbg_rowpass << 16);
+    hw->pad2 = (double)lds->dbg_gathered;
   }
 }
 

@@ -42,6 +42,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--scheme', default='ls-2')
     ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--dist', default='gauss', choices=['gauss', 'relu', 'relu-bn'],
+                    help='input distribution: N(0,1); relu(N(0,1)); per-channel affine of relu (what a BN after a ReLU feeds)')
     args = ap.parse_args()
     dev = 'cuda:0'
     sch = {'ls-1': (1, 1), 'ls-2': (2, 2), 'ls-T': (3, 2), 'gf-2': (4, 2)}[args.scheme]
@@ -49,6 +51,10 @@ def main():
     tot_q = tot_c = tot_f = 0.0
     for c, h, o, stride, count in SHAPES:
         x = torch.randn(n, c, h, h, device=dev)
+        if args.dist != 'gauss':
+            x = x.clamp(min=0)
+        if args.dist == 'relu-bn':
+            x = x * (0.5 + torch.rand(1, c, 1, 1, device=dev)) * 1.7 + torch.randn(1, c, 1, 1, device=dev) * 0.5 - 0.7
         w = torch.randn(o, c, 3, 3, device=dev)
         g = _hip.make_geom(n, c, h, h, o, 3, 3, (stride, stride), (1, 1), (1, 1), 1)
         k = sch[1]

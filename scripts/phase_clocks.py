@@ -7,8 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, 'ml-quant_amd')]
 import torch
 from quant import _hip
 lib = _hip.lib()
-names = {0: 'start', 1: 'pass0 done', 2: 'solve entry', 3: 'L1 scan+flag done', 4: 'gather done', 5: 'wave path done',
-         6: 'block path done', 8: 'pass1 done', 9: 'end'}
+names = {10: 'solve start', 11: 'slots loaded', 13: 'roles set', 4: 'gather done', 5: 'wave path done', 6: 'block path done', 12: 'argmin done'}
 for c, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     n = 256
     x = torch.randn(n, c, h, h, device='cuda')
@@ -20,5 +19,5 @@ for c, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     torch.cuda.synchronize()
     buf = (ctypes.c_longlong * 32)()
     lib.lsq_debug_read_clocks(buf)
-    t0 = buf[0]
-    print(f'C={c} H={h}: ' + ', '.join(f'{names[i]}={buf[i] - t0}' for i in sorted(names) if buf[i]))
+    t0 = buf[10]
+    print(f'C={c} H={h}: ' + ', '.join(f'{names[i]}={buf[i] - t0}' for i in names if buf[i]))
