@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 1
+#define LSQ_ABI_VERSION 2
 
 /* quantization schemes (quant/binary/binary_conv.py:99-101) */
 enum {
@@ -87,6 +87,9 @@ int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
  *   scheme,k     LS1: k=1; LS2, LST: k=2; GF: k = number of bits (1..LSQ_MAX_PLANES)
  *   skip         sub-sampling stride of the v1 search (quantization.py:63; 3 in the reference)
  *   clamp_alpha  symmetric clamp bound, or a negative value for clamp_identity
+ *   pre_scale, pre_shift  NULL, or [C] per-channel affine applied before the clamp, x' = x*s[c] + t[c]:
+ *                the eval-mode BatchNorm2d that feeds the layer (quant/models/resnet.py:182,185) folded
+ *                into the read, s = gamma / sqrt(var + eps), t = beta - mean * s
  *   forced       NULL, or [k][N] scales to use instead of solving (eval with moving average,
  *                activation_quantization.py:90-98)
  *   planes       out, [k] activation planes laid out as described above (halo pre-zeroed)
@@ -94,7 +97,8 @@ int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
  *   workspace    lsq_solver_workspace_bytes(N) bytes, 8-byte aligned (LS2 / LST without forced scales)
  */
 int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
-                  float clamp_alpha, const float* forced, uint64_t* planes, float* scales,
+                  float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                  const float* forced, uint64_t* planes, float* scales,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bytes of scratch the LS2 / LST scale solve needs for `rows` rows (slot records handed from the
@@ -129,11 +133,15 @@ int lsq_pack_weight(const float* w, const lsq_conv_geom* g, int k, const float* 
  * which equals F.conv2d(x_q, w_q, bias, ...) of binary_conv.py:165-173 for
  * x_q = sum_p xs_p b_p, w_q = sum_q ws_q s_q (exact integer inner products).
  *   kx, kw_planes  number of activation / weight planes
+ *   relu, res_pre, res_post   optional fused block epilogue, y = relu?(conv + bias + res_pre) + res_post
+ *                  (the non-linearity and shortcut additions of quant/models/resnet.py:95-100, :182-190);
+ *                  residuals are [N][O][Ho][Wo] fp32 or NULL
  *   y              out, [N][O][Ho][Wo] fp32
  */
 int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
                     const uint64_t* wbits, const int32_t* wsum, int kw_planes,
                     const float* wscales, const float* bias, const lsq_conv_geom* g,
+                    int relu, const float* res_pre, const float* res_post,
                     float* y, void* stream);
 
 /*
@@ -141,8 +149,10 @@ int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
  *   y[n][o] = bias[o] + sum_q ws[q][o] * conv(clamp(x), wplane_q)[n][o]
  * Replaces F.conv2d(x, w_q, ...) of binary_conv.py:165-173 when x_quant == 'fp'.
  */
-int lsq_signw_conv2d(const float* x, float clamp_alpha, const uint64_t* wbits, int kw_planes,
+int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                     const uint64_t* wbits, int kw_planes,
                      const float* wscales, const float* bias, const lsq_conv_geom* g,
+                     int relu, const float* res_pre, const float* res_post,
                      float* y, void* stream);
 
 #ifdef __cplusplus

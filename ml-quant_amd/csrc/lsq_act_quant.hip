@@ -67,6 +67,8 @@ struct Args {
   int scheme, k, skip;
   float alpha;
   const float* forced;      // [k][N] or null
+  const float* pre_scale;   // [C] or null: x' = x * pre_scale[c] + pre_shift[c] before the clamp (folded eval BN)
+  const float* pre_shift;
   unsigned long long* planes;
   long long plane_words;    // words of one plane (all rows)
   long long row_words;      // words of one row of one plane
@@ -441,8 +443,14 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
         const int cc = cb + u;
         if (cc < nch) {
           float x[VEC];
+          if (a.pre_scale) {            // folded batch norm: one fma per element, scale/shift wave-uniform
+            const float sc = a.pre_scale[c0 + cc], sh = a.pre_shift[c0 + cc];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(vals[u][v], a.alpha);
+            for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(fmaf(vals[u][v], sc, sh), a.alpha);
+          } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(vals[u][v], a.alpha);
+          }
           body(cc, x, rem);
           if constexpr (NEED_REM) {
             rem += step;
@@ -549,7 +557,15 @@ __device__ __forceinline__ void for_each_row_key(const Args& a, const float* __r
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (j0 + (unsigned)u * kThreads < n) f(abs_key(clamp_sym(v[u], a.alpha)));
+      if (j0 + (unsigned)u * kThreads < n) {
+        float xv = v[u];
+        if (a.pre_scale) {
+          const long long flat = (long long)(j0 + (unsigned)u * kThreads) * skip;
+          const int c = (int)(flat / ((long long)a.H * a.W));
+          xv = fmaf(xv, a.pre_scale[c], a.pre_shift[c]);
+        }
+        f(abs_key(clamp_sym(xv, a.alpha)));
+      }
   }
 }
 
@@ -1054,13 +1070,17 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
   // and for skip = 3 exactly one of the first three elements is sub-sampled (plus the fourth when
   // i % 3 == 0).  Two phases per batch of U loads keep the returning LDS atomics in flight together.
   const long long M = a.row_elems;
-  const bool vec_ok = a.skip == 3 && (M % 4) == 0 && (((uintptr_t)xrow) % 16) == 0 && n_rg != 0u;
+  const bool vec_ok = a.skip == 3 && (M % 4) == 0 && (((uintptr_t)xrow) % 16) == 0 && n_rg != 0u &&
+                      (a.pre_scale == nullptr || ((a.H * a.W) % 4) == 0);
   if (!vec_ok) {
     for_each_row_key(a, xrow, n, take);
     return;
   }
   const float4* __restrict__ row4 = reinterpret_cast<const float4*>(xrow);
   const unsigned nvec = (unsigned)(M / 4);
+  const bool affine = a.pre_scale != nullptr;
+  const unsigned qv = (unsigned)(a.H * a.W) / 4u;      // float4s per channel (H*W % 4 == 0 checked below)
+  const float qinv = 1.0f / (float)(qv ? qv : 1u);
   constexpr int U = 8;
   unsigned rem0 = threadIdx.x % 3u;                  // (i % 3) for i = tid; advances by 1024 % 3 = 1 per step
   for (unsigned i0 = threadIdx.x; i0 < nvec; i0 += kThreads * U) {
@@ -1079,6 +1099,15 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
       has[0] = live;
       xs[1] = v[u].w;
       has[1] = live && rem == 0u;
+      if (affine) {                 // channel of this float4: i / qv via a reciprocal, corrected
+        const unsigned i = min(i0 + (unsigned)u * kThreads, nvec - 1u);
+        unsigned c = (unsigned)((float)i * qinv);
+        if ((c + 1u) * qv <= i) ++c;
+        if (c * qv > i) --c;
+        const float sc = a.pre_scale[c], sh = a.pre_shift[c];
+        xs[0] = fmaf(xs[0], sc, sh);
+        xs[1] = fmaf(xs[1], sc, sh);
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const unsigned key = abs_key(clamp_sym(xs[e], a.alpha));
@@ -1430,7 +1459,8 @@ extern "C" int64_t lsq_act_plane_words(const lsq_conv_geom* g) {
 extern "C" int64_t lsq_solver_workspace_bytes(int64_t rows) { return rows > 0 ? rows * kWsRow : -1; }
 
 extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
-                             float clamp_alpha, const float* forced, uint64_t* planes, float* scales,
+                             float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                             const float* forced, uint64_t* planes, float* scales,
                              void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !planes || !scales) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
@@ -1450,6 +1480,9 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   a.Hp = g->H + 2 * g->pad_h; a.Wp = g->W + 2 * g->pad_w;
   a.scheme = scheme; a.k = k; a.skip = skip; a.alpha = clamp_alpha;
   a.forced = forced;
+  if ((pre_scale == nullptr) != (pre_shift == nullptr)) return LSQ_E_NULL;
+  a.pre_scale = pre_scale;
+  a.pre_shift = pre_shift;
   a.planes = (unsigned long long*)planes;
   a.row_words = (long long)a.Gt * a.Hp * a.Wp;
   a.plane_words = a.row_words * g->N;

@@ -28,11 +28,17 @@ struct SwArgs {
   const unsigned long long* wbits;     // [taps][Gg][Opad]  (one weight plane)
   const float* wscale;                 // [O]
   const float* bias;                   // [O] or null
+  const float* pre_scale;              // [C] or null (folded eval batch norm)
+  const float* pre_shift;
   float* y;                            // [N][O][Ho][Wo]
   float alpha;
   int N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
   int Gg, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
   int accumulate;
+  int final_pass;
+  int relu;                            // epilogue: y = relu(conv + bias + res_pre) + res_post
+  const float* res_pre;                // [N][O][Ho][Wo] or null
+  const float* res_post;
 };
 
 union Frag {
@@ -88,7 +94,13 @@ __global__ __launch_bounds__(256) void signw_conv_kernel(SwArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int c = c0 + 8 * kh8 + j;
-          xv[j] = (inb && c < a.cg) ? clamp_sym(xp[(long long)c * HW], a.alpha) : 0.f;
+          float t = 0.f;
+          if (inb && c < a.cg) {
+            t = xp[(long long)c * HW];
+            if (a.pre_scale) t = fmaf(t, a.pre_scale[grp * a.cg + c], a.pre_shift[grp * a.cg + c]);
+            t = clamp_sym(t, a.alpha);
+          }
+          xv[j] = t;
         }
         Frag bhi, blo;
 #pragma unroll
@@ -128,7 +140,14 @@ __global__ __launch_bounds__(256) void signw_conv_kernel(SwArgs a) {
         const int o = o0 + ol;
         const float v = acc[i][j] * a.wscale[o];
         const float base = a.accumulate ? yp[(long long)ol * HoWo] : (a.bias ? a.bias[o] : 0.f);
-        yp[(long long)ol * HoWo] = base + v;
+        float out = base + v;
+        if (a.final_pass) {
+          const long long yi = ((long long)n * a.O + o) * HoWo + r;
+          if (a.res_pre) out += a.res_pre[yi];
+          if (a.relu) out = fmaxf(out, 0.f);
+          if (a.res_post) out += a.res_post[yi];
+        }
+        yp[(long long)ol * HoWo] = out;
       }
     }
   }
@@ -139,16 +158,20 @@ __global__ __launch_bounds__(256) void signw_conv_kernel(SwArgs a) {
 
 using namespace lsq;
 
-extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const uint64_t* wbits, int kw_planes,
-                                const float* wscales, const float* bias, const lsq_conv_geom* g, float* y,
-                                void* stream) {
+extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                                const uint64_t* wbits, int kw_planes, const float* wscales, const float* bias,
+                                const lsq_conv_geom* g, int relu, const float* res_pre, const float* res_post,
+                                float* y, void* stream) {
   if (!x || !wbits || !wscales || !y) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
   if (kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
   const int Ho = out_h(g), Wo = out_w(g);
   if (Ho <= 0 || Wo <= 0) return LSQ_E_SHAPE;
   SwArgs a = {};
+  if ((pre_scale == nullptr) != (pre_shift == nullptr)) return LSQ_E_NULL;
   a.x = x; a.bias = bias; a.y = y; a.alpha = clamp_alpha;
+  a.pre_scale = pre_scale; a.pre_shift = pre_shift;
+  a.relu = relu; a.res_pre = res_pre; a.res_post = res_post;
   a.N = g->N; a.C = g->C; a.H = g->H; a.W = g->W; a.O = g->O; a.KH = g->KH; a.KW = g->KW;
   a.sh = g->stride_h; a.sw = g->stride_w; a.ph = g->pad_h; a.pw = g->pad_w; a.dh = g->dil_h; a.dw = g->dil_w;
   a.cg = g->C / g->groups;
@@ -168,6 +191,7 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const uint64_
     a.wbits = (const unsigned long long*)wbits + (long long)q * wplane_words;
     a.wscale = wscales + (long long)q * g->O;
     a.accumulate = q ? 1 : 0;
+    a.final_pass = q == kw_planes - 1 ? 1 : 0;
     dim3 grid((unsigned)((total + 127) / 128), (unsigned)(g->groups * a.tiles_per_group));
     if (otw == 4) hipLaunchKernelGGL((signw_conv_kernel<4>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((signw_conv_kernel<2>), grid, dim3(256), 0, st, a);

@@ -33,6 +33,10 @@ struct ConvArgs {
   int N, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
   int Gg, Gt, Hp, Wp, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
   int accumulate;
+  int final_pass;                      // last launch of a multi-plane sequence: apply the epilogue
+  int relu;                            // epilogue: y = relu(conv + bias + res_pre) + res_post
+  const float* res_pre;                // [N][O][Ho][Wo] or null
+  const float* res_post;
   int tap_xoff[64];                    // (kh*dil_h)*Wp + kw*dil_w per tap
 };
 
@@ -137,7 +141,14 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
       for (int p = 0; p < KX; ++p) v += xs[p] * (float)(full - 2 * acc[p][o] + corr[o]);
       v *= a.wscale[o0 + o];
       const float base = a.accumulate ? yp[(long long)o * HoWo] : (a.bias ? a.bias[o0 + o] : 0.f);
-      yp[(long long)o * HoWo] = base + v;
+      float out = base + v;
+      if (a.final_pass) {        // fused block epilogue (non-linearity and shortcut adds of resnet.py:182-190)
+        const long long yi = ((long long)n * a.O + o0 + o) * HoWo + r;
+        if (a.res_pre) out += a.res_pre[yi];
+        if (a.relu) out = fmaxf(out, 0.f);
+        if (a.res_post) out += a.res_post[yi];
+      }
+      yp[(long long)o * HoWo] = out;
     }
   }
 }
@@ -157,7 +168,8 @@ using namespace lsq;
 
 extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
                                const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
-                               const lsq_conv_geom* g, float* y, void* stream) {
+                               const lsq_conv_geom* g, int relu, const float* res_pre, const float* res_post,
+                               float* y, void* stream) {
   if (!xplanes || !xscales || !wbits || !wsum || !wscales || !y) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
   if (kx < 1 || kx > LSQ_MAX_PLANES || kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
@@ -181,6 +193,9 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
     for (int kw = 0; kw < g->KW; ++kw) a.tap_xoff[kh * g->KW + kw] = kh * g->dil_h * a.Wp + kw * g->dil_w;
   a.bias = bias;
   a.y = y;
+  a.relu = relu;
+  a.res_pre = res_pre;
+  a.res_post = res_post;
   const long long wplane_words = lsq_weight_plane_words(g);
   const int taps = g->KH * g->KW;
   hipStream_t st = (hipStream_t)stream;
@@ -194,6 +209,7 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
       a.wsum = wsum + (long long)q * g->O * taps;
       a.wscale = wscales + (long long)q * g->O;
       a.accumulate = first ? 0 : 1;
+      a.final_pass = (q == kw_planes - 1 && p0 + np >= kx) ? 1 : 0;
       const int e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
       if (e) return e;
       first = false;

@@ -16,6 +16,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 _lock = threading.Lock()
 _lib = None
 
+ABI_VERSION = 2
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 
@@ -50,7 +51,7 @@ def _declare(lib):
     lib.lsq_weight_plane_words.restype = i64
     lib.lsq_weight_plane_words.argtypes = [gp]
     lib.lsq_act_quant.restype = i32
-    lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.lsq_solver_workspace_bytes.restype = i64
     lib.lsq_solver_workspace_bytes.argtypes = [i64]
     lib.lsq_solve_rows.restype = i32
@@ -58,9 +59,9 @@ def _declare(lib):
     lib.lsq_pack_weight.restype = i32
     lib.lsq_pack_weight.argtypes = [vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_xnor_conv2d.restype = i32
-    lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, vp, vp]
+    lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_signw_conv2d.restype = i32
-    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, i32, vp, vp, gp, vp, vp]
+    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
 
 
 def lib():
@@ -75,7 +76,7 @@ def lib():
                         '(or `make -C ml-quant_amd/csrc`). The HIP path has no fallback.')
                 handle = ctypes.CDLL(_LIB_PATH)
                 _declare(handle)
-                if handle.lsq_abi_version() != 1:
+                if handle.lsq_abi_version() != ABI_VERSION:
                     raise LsqHipError('liblsq_hip.so ABI version mismatch')
                 _lib = handle
     return _lib
@@ -162,14 +163,17 @@ def solver_workspace(rows: int, device) -> torch.Tensor:
 
 
 def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, alpha: float,
-              planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None) -> None:
+              planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None,
+              pre: Optional[tuple] = None) -> None:
+    """pre = (scale[C], shift[C]) folds an eval-mode batch norm into the read."""
     x = _f32c(x)
     ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) and forced is None else None
     m = geom.C * geom.H * geom.W
     with _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8)):     # x read once + k bit planes written
-        check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha), ptr(forced),
-                                  planes.data_ptr(), scales.data_ptr(), ptr(ws), 0 if ws is None else ws.numel(),
-                                  stream_ptr()), 'lsq_act_quant')
+        check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha),
+                                  None if pre is None else pre[0].data_ptr(), None if pre is None else pre[1].data_ptr(),
+                                  ptr(forced), planes.data_ptr(), scales.data_ptr(), ptr(ws),
+                                  0 if ws is None else ws.numel(), stream_ptr()), 'lsq_act_quant')
 
 
 def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0):
@@ -208,20 +212,26 @@ def out_hw(geom: ConvGeom):
 
 
 def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: torch.Tensor, wsum: torch.Tensor,
-                wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
+                wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor,
+                relu: bool = False, res_pre: Optional[torch.Tensor] = None,
+                res_post: Optional[torch.Tensor] = None) -> None:
+    """y = relu?(conv + bias + res_pre) + res_post (the fused block epilogue is optional)."""
     m = geom.C * geom.H * geom.W
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
     with _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs):   # planes read + fp32 output written
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
-                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(),
-                                    stream_ptr()), 'lsq_xnor_conv2d')
+                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu),
+                                    ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr()), 'lsq_xnor_conv2d')
 
 
 def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,
-                 bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor) -> None:
+                 bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor, pre: Optional[tuple] = None,
+                 relu: bool = False, res_pre: Optional[torch.Tensor] = None,
+                 res_post: Optional[torch.Tensor] = None) -> None:
     x = _f32c(x)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
     with _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel(), flops):     # fp32 input read + fp32 output written
-        check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), wbits.data_ptr(), wscales.shape[0],
-                                     wscales.data_ptr(), ptr(bias), ctypes.byref(geom), y.data_ptr(), stream_ptr()),
-              'lsq_signw_conv2d')
+        check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), None if pre is None else pre[0].data_ptr(),
+                                     None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wscales.shape[0],
+                                     wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu), ptr(res_pre),
+                                     ptr(res_post), y.data_ptr(), stream_ptr()), 'lsq_signw_conv2d')

@@ -149,9 +149,42 @@ class QuantConv2d(nn.Conv2d):
             self._hip_cache['w'] = hit
         return hit[1], hit[2], hit[3]
 
-    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+    def fused_forward(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
+                      res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``relu?(self(pre_bn(x)) + res_pre) + res_post`` -- one residual-block half (quant/models/resnet.py:
+        95-100, 182-190).  On the HIP path the eval-mode batch norm is folded into the quantizer's read
+        and the non-linearity / shortcut additions into the convolution's epilogue, so none of them is
+        a separate pass over HBM; elsewhere it is the plain composition of the modules."""
+        if self._wants_hip(x) and (pre_bn is None or (not pre_bn.training and pre_bn.track_running_stats)):
+            return self._forward_hip(x, pre_bn, relu, res_pre, res_post)
+        y = self(x if pre_bn is None else pre_bn(x))
+        if res_pre is not None:
+            y = y + res_pre
+        if relu:
+            y = torch.relu(y)
+        return y if res_post is None else y + res_post
+
+    def _folded_bn(self, bn: nn.BatchNorm2d):
+        """(scale, shift) with bn(x) = x * scale + shift in eval mode; cached on the BN's buffer versions."""
+        tensors = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+        stamp = (id(bn), bn.eps) + tuple((t._version, t.data_ptr()) for t in tensors)
+        hit = self._hip_cache.get('bn')
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+                scale = inv * bn.weight.float() if bn.affine else inv
+                shift = (bn.bias.float() if bn.affine else 0) - bn.running_mean.float() * scale
+            hit = (stamp, scale.contiguous(), shift.contiguous())
+            self._hip_cache['bn'] = hit
+        return hit[1], hit[2]
+
+    def _forward_hip(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
+                     res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None) -> torch.Tensor:
         from quant import _hip
         x = x.detach()
+        pre = None if pre_bn is None else self._folded_bn(pre_bn)
+        res_pre = None if res_pre is None else res_pre.detach().contiguous()
+        res_post = None if res_post is None else res_post.detach().contiguous()
         n, c, h, w = x.shape
         kh, kw = self.kernel_size
         geom = _hip.make_geom(n, c, h, w, self.out_channels, kh, kw, self.stride, self.padding,
@@ -161,7 +194,7 @@ class QuantConv2d(nn.Conv2d):
         y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
         bias = None if self.bias is None else self.bias.detach()
         if self.x_quant == 'fp':
-            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y)      # clamp fused into the load
+            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y, pre, relu, res_pre, res_post)
             return y
         xq = self.x_approximate
         k = xq.n_planes
@@ -177,7 +210,7 @@ class QuantConv2d(nn.Conv2d):
         forced = xq.eval_scales(n)
         if forced is not None:
             forced = forced.to(device=x.device, dtype=torch.float32).contiguous()
-        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced)
-        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y)
+        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced, pre)
+        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post)
         self.last_act_scales = scales
         return y

@@ -56,7 +56,7 @@ class RegularBasicBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.nonlin1(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y)) + self.shortcut(x)
-        return self.nonlin2(y)
+        return self.nonlin2(y)          # (batch norm follows the conv here: nothing to fold into the quantizer)
 
 
 class XnorBasicBlock(nn.Module):
@@ -78,6 +78,15 @@ class XnorBasicBlock(nn.Module):
         self.shortcut = _projection(in_planes, planes, stride, bias=True)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _fusable(self, x):
+            # eval on the GPU: bn -> quantizer and conv -> relu -> (+shortcut) each collapse into one
+            # kernel pair (QuantConv2d.fused_forward); same arithmetic as the modular path below
+            sc = self.shortcut(x)
+            if self.double_shortcut:
+                first = self.conv1.fused_forward(x, self.bn1, relu=True, res_post=sc)
+                return self.conv2.fused_forward(first, self.bn2, relu=True, res_post=first)
+            first = self.conv1.fused_forward(x, self.bn1, relu=True)
+            return self.conv2.fused_forward(first, self.bn2, relu=True, res_pre=sc)
         first = self.nonlin1(self.conv1(self.bn1(x)))
         if self.double_shortcut:
             first = first + self.shortcut(x)
@@ -85,6 +94,15 @@ class XnorBasicBlock(nn.Module):
         second = self.conv2(self.bn2(first)) + self.shortcut(x)
         return self.nonlin2(second)
 
+
+def _fusable(block: nn.Module, x: torch.Tensor) -> bool:
+    """Fused HIP path: eval mode, CUDA input, ReLU non-linearities, weights binarized (QuantConv2d decides)."""
+    return (not block.training and x.is_cuda and FUSE_BLOCKS and isinstance(block.nonlin1, nn.ReLU)
+            and isinstance(block.nonlin2, nn.ReLU) and block.conv1._wants_hip(x))
+
+
+#: set to False to run residual blocks as separate BN / QuantConv2d / ReLU / add modules on the GPU too
+FUSE_BLOCKS = True
 
 _BLOCKS = {'regular': RegularBasicBlock, 'xnor': XnorBasicBlock}
 

@@ -377,17 +377,22 @@ def test_resnet18_every_layer_and_logits(golden, tag, shape):
     the SAME input with the GPU's scales (bit planes exact => 1e-4), its v1 equals the exact
     oracle's, and the free-running logits track the reference's (CPU-vs-GPU differences in the
     fp stem / batch norms flip a few near-zero signs, so end to end is cosine, not 1e-4)."""
+    import quant.models.resnet as R
     from quant.binary.binary_conv import QuantConv2d
     g = golden('f6_models')
     model = _build_model(g.json(tag + '_arch'), seed=1).to(DEV)
     x = detgen.normal(tag + '.x', shape).to(DEV)
     rec = []
+    R.FUSE_BLOCKS = False           # module-by-module so that every QuantConv2d's input can be captured
 
     def hook(mod, args, out):
         rec.append((mod, args[0].detach().cpu(), out.detach().cpu(), mod.last_act_scales.clone().cpu()))
     hooks = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, QuantConv2d)]
-    with torch.no_grad():
-        free = model(x).cpu()
+    try:
+        with torch.no_grad():
+            free = model(x).cpu()
+    finally:
+        R.FUSE_BLOCKS = True
     for h in hooks:
         h.remove()
     assert len(rec) == 16
@@ -429,6 +434,76 @@ def test_xnor_block_vs_reference(golden):
     ref = g['block_y']
     assert torch.nn.functional.cosine_similarity(y.flatten(), ref.flatten(), dim=0) > 0.9999
     assert rel_err(y, ref) <= 5e-2
+
+
+@pytest.mark.parametrize('xs', ['ls-2', 'ls-1', 'ls-T', 'fp'])
+def test_fused_bn_fold_and_epilogue_exact(xs):
+    """Folded batch norm + fused relu / residual epilogue against the oracle.  Inputs, scale and shift are
+    dyadic so that x*s+t is exact whether it is evaluated as one fma (GPU) or mul+add (CPU): every bit
+    plane must then match and the output obey the 1e-4 bound, for all three epilogue shapes."""
+    import quant.models.resnet as R
+    from quant.binary.binary_conv import QuantConv2d
+    x = torch.round(detgen.normal('gpu.fuse.x', (3, 64, 12, 12), scale=1.5) * 32) / 32
+    sc = torch.tensor([0.5, 1.0, 2.0, 1.0] * 16)
+    sh = torch.round(detgen.normal('gpu.fuse.t', (64,)) * 8) / 8
+    res = detgen.normal('gpu.fuse.r', (3, 64, 12, 12))
+    clamp = {'kind': 'symmetric', 'alpha': 2}
+    conv = QuantConv2d(xs, 'ls-1', 64, 64, 3, clamp, padding=1)
+    detgen.fill_module(conv, seed=21)
+    bn = torch.nn.BatchNorm2d(64)
+    with torch.no_grad():
+        conv.w_approximate.v1.copy_(P.weight_scales(conv.weight, 'ls-1')[0])
+        bn.running_var.fill_(1.0 - bn.eps)          # 1/sqrt(var + eps) = 1 exactly
+        bn.weight.copy_(sc)
+        bn.running_mean.zero_()
+        bn.bias.copy_(sh)
+    conv.eval().to(DEV)
+    bn.eval().to(DEV)
+    xin = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    w, b = conv.weight.detach().cpu(), conv.bias.detach().cpu()
+    for relu, pre, post in ((True, False, True), (True, True, False), (False, False, False)):
+        with torch.no_grad():
+            y = conv.fused_forward(x.to(DEV), bn, relu=relu, res_pre=res.to(DEV) if pre else None,
+                                   res_post=res.to(DEV) if post else None).cpu()
+        inj = None
+        if xs != 'fp':
+            s_gpu = conv.last_act_scales.clone().cpu()
+            inj = list(s_gpu[:1]) if xs == 'ls-T' else list(s_gpu)
+            xc = xin.clamp(-2, 2)
+            if xs in ('ls-2', 'ls-T'):
+                assert np.array_equal(s_gpu[0].numpy(), E.solve_rows(xc.numpy(), xs == 'ls-T', 3))
+        ref = P.quant_conv2d(xin, w, b, xs, 'ls-1', [conv.w_approximate.v1.cpu()], clamp, 1, 1, x_scales=inj)
+        if pre:
+            ref = ref + res
+        if relu:
+            ref = torch.relu(ref)
+        if post:
+            ref = ref + res
+        assert rel_err(y, ref) <= TOL, (xs, relu, pre, post, rel_err(y, ref))
+
+
+def test_fused_blocks_agree_with_modular_path(golden):
+    """Whole ResNet-18: fused residual blocks (BN folded, relu/add in the conv epilogue) against the same
+    model run module by module on the GPU and against the reference's logits."""
+    import quant.models.resnet as R
+    g = golden('f6_models')
+    for tag, shape in (('imagenet_ls1w_ls2a', (2, 3, 64, 64)), ('cifar100_ls1', (4, 3, 32, 32)),
+                       ('imagenet_ls1w_fpa', (2, 3, 64, 64))):
+        model = _build_model(g.json(tag + '_arch'), seed=1).to(DEV)
+        x = detgen.normal(tag + '.x', shape).to(DEV)
+        with torch.no_grad():
+            R.FUSE_BLOCKS = True
+            fused = model(x).cpu()
+            R.FUSE_BLOCKS = False
+            try:
+                modular = model(x).cpu()
+            finally:
+                R.FUSE_BLOCKS = True
+        ref = g[tag + '_logits']
+        cos = torch.nn.functional.cosine_similarity
+        assert cos(fused.flatten(), modular.flatten(), dim=0) > 0.9995, tag
+        assert cos(fused.flatten(), ref.flatten(), dim=0) > 0.999, tag
+        assert rel_err(fused, ref) <= 0.1, (tag, rel_err(fused, ref))
 
 
 # ------------------------------------------------------------------------------------------------
