@@ -93,14 +93,24 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
           for (int p = 0; p < KX; ++p) xn[p] = xp[p * plane_stride + noff];
         }
       }
+      // low halves of all OT x KX words first, then the high halves: the two popcounts that feed one
+      // accumulator end up 2*OT*KX instructions apart instead of back to back (v_bcnt is a 2-pass op)
+      unsigned long long wv[OT];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) wv[o] = wp[o];            // wave-uniform: scalar loads, SGPR operands
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
-        const unsigned long long wv = wp[o];           // wave-uniform: scalar load, SGPR operand
 #pragma unroll
         for (int p = 0; p < KX; ++p) {
-          const unsigned lo = (unsigned)xa[p] ^ (unsigned)wv, hi = (unsigned)(xa[p] >> 32) ^ (unsigned)(wv >> 32);
-          // v_bcnt_u32_b32 accumulates: acc = popcount(x) + acc, one VALU op per 32 bits
-          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[p][o]) : "v"(lo));
+          const unsigned lo = (unsigned)xa[p] ^ (unsigned)wv[o];
+          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[p][o]) : "v"(lo));   // acc = popcount(lo) + acc
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int p = 0; p < KX; ++p) {
+          const unsigned hi = (unsigned)(xa[p] >> 32) ^ (unsigned)(wv[o] >> 32);
           asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[p][o]) : "v"(hi));
         }
       }
