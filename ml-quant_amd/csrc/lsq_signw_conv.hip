@@ -153,6 +153,191 @@ __global__ __launch_bounds__(256) void signw_conv_kernel(SwArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Tiled version: a 256-thread workgroup computes BM out-channels x 128 pixels.  Per K-chunk (one tap,
+// 32 channels) the block stages into LDS, ONCE for its four waves, (a) the +-1 weight fragment expanded
+// from 4 bytes of the packed plane per out-channel and (b) the activation chunk already clamped /
+// batch-norm-folded and split into bf16 hi and lo, both as [row][32 k] with a 16-byte row pad so that
+// the 16-byte MFMA fragment reads of a 32-lane group hit distinct banks.  Global loads of chunk i+1
+// are issued before the MFMAs of chunk i and written to the other LDS buffer after them (one barrier
+// per chunk).  Each wave owns TM x TN 32x32 tiles: 2*TM*TN*2 MFMAs per chunk against
+// (TM + 2*TN)*2 fragment reads.
+constexpr int kKC = 32;                         // channels per K-chunk
+constexpr int kRowB = kKC * 2 + 16;             // LDS row pitch in bytes (64 data + 16 pad)
+constexpr int kBN = 128;                        // pixels per block
+
+template <int BM, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == kBN, "tile shape");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + 2 * kBN) * kRowB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const int col = lane & 31, kh8 = lane >> 5;
+  const int tile = blockIdx.y;
+  const int grp = tile / a.tiles_per_group;
+  const int t = tile - grp * a.tiles_per_group;
+  const int o_pad0 = grp * a.og_pad + t * BM;
+  const int o0 = grp * a.og + t * BM;
+  const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+  const long long total = (long long)a.N * HoWo;
+  const int taps = a.KH * a.KW;
+  const int cchunks = (a.cg + kKC - 1) / kKC;
+  const int nchunks = taps * cchunks;
+
+  // ---- staging roles
+  // activations: thread -> pixel (tid & 127), k half (tid >> 7) of 16 channels
+  const int sp = tid & (kBN - 1), skh = tid >> 7;
+  const long long spix = (long long)blockIdx.x * kBN + sp;
+  const bool sp_valid = spix < total;
+  const long long spc = sp_valid ? spix : 0;
+  const int sn = (int)(spc / HoWo);
+  const int sr = (int)(spc - (long long)sn * HoWo);
+  const int sho = sr / a.Wo, swo = sr - sho * a.Wo;
+  const float* xg = a.x + ((long long)sn * a.C + (long long)grp * a.cg) * HW;
+  // weights: thread -> out-channel (tid % BM), k part (tid / BM) of KC / (256 / BM) channels
+  constexpr int WPARTS = 256 / BM;              // 2 (BM = 128) or 4 (BM = 64)
+  constexpr int WK = kKC / WPARTS;              // 16 or 8 channels per thread
+  const int so = tid % BM, swp = tid / BM;
+  const bool so_valid = t * BM + so < a.og_pad;
+
+  float xr[16];
+  unsigned wr = 0;
+  auto load_chunk = [&](int ch) {
+    const int tap = ch / cchunks, cc = ch - tap * cchunks;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int hi = sho * a.sh - a.ph + kh * a.dh, wi = swo * a.sw - a.pw + kw * a.dw;
+    const bool inb = sp_valid && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+    const int cbase = cc * kKC + skh * 16;
+    // all 16 loads are issued unconditionally (out-of-image / padded channels read a valid dummy
+    // address and are zeroed afterwards): a load inside a divergent branch is waited for on the spot,
+    // which serialises 16 memory latencies per chunk
+    const float* xp = inb ? xg + (long long)hi * a.W + wi : xg;
+    float raw[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) raw[j] = xp[(long long)min(cbase + j, a.cg - 1) * HW];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = cbase + j;
+      float v = raw[j];
+      if (a.pre_scale) {
+        const int cs = grp * a.cg + min(c, a.cg - 1);
+        v = fmaf(v, a.pre_scale[cs], a.pre_shift[cs]);
+      }
+      v = clamp_sym(v, a.alpha);
+      xr[j] = (inb && c < a.cg) ? v : 0.f;
+    }
+    const int c0 = cc * kKC;
+    const int g = c0 >> 6;
+    const int bit0 = (c0 & 63) + swp * WK;
+    const unsigned long long wv =
+        so_valid ? a.wbits[((long long)tap * a.Gg + g) * a.opad_total + o_pad0 + so] : 0ull;
+    wr = (unsigned)(wv >> bit0) & ((1u << WK) - 1u);
+  };
+  auto store_chunk = [&](int buf) {
+    unsigned char* sA = smem[buf];
+    unsigned char* sBh = sA + BM * kRowB;
+    unsigned char* sBl = sBh + kBN * kRowB;
+    // activations -> bf16 hi (truncation) and lo (rounded remainder), 16 values = 32 bytes each
+    unsigned hi[8], lo[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const unsigned x0 = __float_as_uint(xr[2 * p]), x1 = __float_as_uint(xr[2 * p + 1]);
+      const unsigned h0 = x0 & 0xFFFF0000u, h1 = x1 & 0xFFFF0000u;
+      const unsigned l0 = __float_as_uint(xr[2 * p] - __uint_as_float(h0));
+      const unsigned l1 = __float_as_uint(xr[2 * p + 1] - __uint_as_float(h1));
+      hi[p] = (h0 >> 16) | h1;
+      lo[p] = ((l0 + 0x7FFFu + ((l0 >> 16) & 1u)) >> 16) | ((l1 + 0x7FFFu + ((l1 >> 16) & 1u)) & 0xFFFF0000u);
+    }
+    uint4* dh = reinterpret_cast<uint4*>(sBh + sp * kRowB + skh * 32);
+    uint4* dl = reinterpret_cast<uint4*>(sBl + sp * kRowB + skh * 32);
+    dh[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dh[1] = make_uint4(hi[4], hi[5], hi[6], hi[7]);
+    dl[0] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    dl[1] = make_uint4(lo[4], lo[5], lo[6], lo[7]);
+    // weights: WK sign bits -> WK bf16 +-1
+    unsigned* dw = reinterpret_cast<unsigned*>(sA + so * kRowB + swp * WK * 2);
+#pragma unroll
+    for (int p = 0; p < WK / 2; ++p) {
+      const unsigned b0 = (wr >> (2 * p)) & 1u, b1 = (wr >> (2 * p + 1)) & 1u;
+      dw[p] = 0x3F803F80u | ((b0 ^ 1u) << 15) | ((b1 ^ 1u) << 31);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) load_chunk(ch + 1);          // in flight during the MFMAs below
+    const unsigned char* sA = smem[buf];
+    const unsigned char* sBh = sA + BM * kRowB;
+    const unsigned char* sBl = sBh + kBN * kRowB;
+#pragma unroll
+    for (int ks = 0; ks < kKC / 16; ++ks) {
+      Frag af[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sA + ((wm * TM + i) * 32 + col) * kRowB + ks * 32 + kh8 * 16);
+        af[i].u[0] = v.x; af[i].u[1] = v.y; af[i].u[2] = v.z; af[i].u[3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = ((wn * TN + j) * 32 + col) * kRowB + ks * 32 + kh8 * 16;
+        const uint4 vh = *reinterpret_cast<const uint4*>(sBh + row);
+        const uint4 vl = *reinterpret_cast<const uint4*>(sBl + row);
+        bh[j].u[0] = vh.x; bh[j].u[1] = vh.y; bh[j].u[2] = vh.z; bh[j].u[3] = vh.w;
+        bl[j].u[0] = vl.x; bl[j].u[1] = vl.y; bl[j].u[2] = vl.z; bl[j].u[3] = vl.w;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = pixel column, registers = out-channel rows (coalesced 128-byte stores)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long long pix = (long long)blockIdx.x * kBN + (wn * TN + j) * 32 + col;
+    if (pix >= total) continue;
+    const int n = (int)(pix / HoWo);
+    const int r = (int)(pix - (long long)n * HoWo);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ol = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh8;
+        if (t * BM + ol < a.og) {
+          const int o = o0 + ol;
+          const long long yi = ((long long)n * a.O + o) * HoWo + r;
+          const float v = acc[i][j][q] * a.wscale[o];
+          float out = (a.accumulate ? a.y[yi] : (a.bias ? a.bias[o] : 0.f)) + v;
+          if (a.final_pass) {
+            if (a.res_pre) out += a.res_pre[yi];
+            if (a.relu) out = fmaxf(out, 0.f);
+            if (a.res_post) out += a.res_post[yi];
+          }
+          a.y[yi] = out;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace lsq
 
@@ -183,18 +368,18 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
   const long long wplane_words = lsq_weight_plane_words(g);
   const long long total = (long long)g->N * Ho * Wo;
   hipStream_t st = (hipStream_t)stream;
-  // tiles of 128 out-channels when the group is wide enough, else 64 (reads of padded slots beyond
-  // og_pad are avoided by the per-lane guard below: tiles never start beyond og)
-  const int otw = a.og > 64 ? 4 : 2;
-  a.tiles_per_group = (a.og + 32 * otw - 1) / (32 * otw);
+  // 128 out-channels x 128 pixels per workgroup when the group is wide enough, else 64 x 128
+  const bool wide = a.og > 64;
+  const int bm = wide ? 128 : 64;
+  a.tiles_per_group = (a.og + bm - 1) / bm;
   for (int q = 0; q < kw_planes; ++q) {
     a.wbits = (const unsigned long long*)wbits + (long long)q * wplane_words;
     a.wscale = wscales + (long long)q * g->O;
     a.accumulate = q ? 1 : 0;
     a.final_pass = q == kw_planes - 1 ? 1 : 0;
-    dim3 grid((unsigned)((total + 127) / 128), (unsigned)(g->groups * a.tiles_per_group));
-    if (otw == 4) hipLaunchKernelGGL((signw_conv_kernel<4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((signw_conv_kernel<2>), grid, dim3(256), 0, st, a);
+    dim3 grid((unsigned)((total + kBN - 1) / kBN), (unsigned)(g->groups * a.tiles_per_group));
+    if (wide) hipLaunchKernelGGL((signw_conv_tiled<128, 2, 2, 2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((signw_conv_tiled<64, 1, 4, 2, 1>), grid, dim3(256), 0, st, a);
     if (int e = (int)hipGetLastError()) return e;
   }
   return LSQ_OK;
