@@ -423,8 +423,10 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
     // U independent loads are issued before any of them is consumed: LDS atomics in the body
     // would otherwise pin every load to its use and leave one request in flight per lane.
     constexpr int U = 32 / VEC;
+    const bool affine = a.pre_scale != nullptr;
     for (int cb = 0; cb < nch; cb += U) {
       float vals[U][VEC];
+      float scs[U], shs[U];          // folded batch norm of the U channels, requested with the data
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int cc = min(cb + u, nch - 1);
@@ -437,16 +439,17 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
         } else {
           vals[u][0] = src[(long long)cc * HW];
         }
+        scs[u] = affine ? a.pre_scale[c0 + cc] : 1.f;
+        shs[u] = affine ? a.pre_shift[c0 + cc] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int cc = cb + u;
         if (cc < nch) {
           float x[VEC];
-          if (a.pre_scale) {            // folded batch norm: one fma per element, scale/shift wave-uniform
-            const float sc = a.pre_scale[c0 + cc], sh = a.pre_shift[c0 + cc];
+          if (affine) {                 // one fma per element
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(fmaf(vals[u][v], sc, sh), a.alpha);
+            for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(fmaf(vals[u][v], scs[u], shs[u]), a.alpha);
           } else {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(vals[u][v], a.alpha);
@@ -1085,8 +1088,21 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
   unsigned rem0 = threadIdx.x % 3u;                  // (i % 3) for i = tid; advances by 1024 % 3 = 1 per step
   for (unsigned i0 = threadIdx.x; i0 < nvec; i0 += kThreads * U) {
     float4 v[U];
+    float scs[U], shs[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = row4[min(i0 + (unsigned)u * kThreads, nvec - 1u)];
+    for (int u = 0; u < U; ++u) {
+      const unsigned i = min(i0 + (unsigned)u * kThreads, nvec - 1u);
+      v[u] = row4[i];
+      scs[u] = 1.f;
+      shs[u] = 0.f;
+      if (affine) {                 // channel of this float4: i / qv via a reciprocal, corrected
+        unsigned c = (unsigned)((float)i * qinv);
+        if ((c + 1u) * qv <= i) ++c;
+        if (c * qv > i) --c;
+        scs[u] = a.pre_scale[c];
+        shs[u] = a.pre_shift[c];
+      }
+    }
     unsigned keys[U][2], pos[U][2];
     bool tk[U][2];
     unsigned rem = rem0;
@@ -1099,14 +1115,9 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
       has[0] = live;
       xs[1] = v[u].w;
       has[1] = live && rem == 0u;
-      if (affine) {                 // channel of this float4: i / qv via a reciprocal, corrected
-        const unsigned i = min(i0 + (unsigned)u * kThreads, nvec - 1u);
-        unsigned c = (unsigned)((float)i * qinv);
-        if ((c + 1u) * qv <= i) ++c;
-        if (c * qv > i) --c;
-        const float sc = a.pre_scale[c], sh = a.pre_shift[c];
-        xs[0] = fmaf(xs[0], sc, sh);
-        xs[1] = fmaf(xs[1], sc, sh);
+      if (affine) {
+        xs[0] = fmaf(xs[0], scs[u], shs[u]);
+        xs[1] = fmaf(xs[1], scs[u], shs[u]);
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
       const int c = cbase + j;
       float v = raw[j];
       if (a.pre_scale) {
-        const int cs = grp * a.cg + min(c, a.cg - 1);
+        // the channel is the same for all lanes of a wave (k half = tid >> 7): scalar loads
+        const int cs = __builtin_amdgcn_readfirstlane(grp * a.cg + min(c, a.cg - 1));
         v = fmaf(v, a.pre_scale[cs], a.pre_shift[cs]);
       }
       v = clamp_sym(v, a.alpha);
