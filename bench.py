@@ -84,12 +84,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    if 'RANK' in os.environ:                       # launched by torchrun (also with one rank): RCCL process group
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+        dist.barrier()
 
     from quant import _hip
     arch = imagenet_arch(args.act, 3 if args.act == 'ls-2' else 2)
@@ -160,7 +161,7 @@ def main():
         if args.cpu_sample > 0 and world == 1:
             out['cpu_baseline'] = cpu_baseline(arch, model, args.cpu_sample)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

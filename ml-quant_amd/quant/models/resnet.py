@@ -23,12 +23,61 @@ def _check_nonlins(nonlins: List[str]) -> None:
         raise ValueError('There should be 2 non-linearities.')
 
 
+def _eval_fold_ok(mod: nn.Module, bn: nn.BatchNorm2d, x: torch.Tensor) -> bool:
+    return (FUSE_BLOCKS and x.is_cuda and not mod.training and not bn.training and bn.affine
+            and bn.track_running_stats and not (torch.is_grad_enabled() and x.requires_grad))
+
+
+def _folded_conv_bn(owner: nn.Module, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """(weight, bias) of the single convolution equal to ``bn(conv(x))`` in eval mode; cached on ``owner``
+    and rebuilt whenever a parameter or running statistic changes."""
+    tensors = [conv.weight, bn.running_mean, bn.running_var, bn.weight, bn.bias] + \
+        ([conv.bias] if conv.bias is not None else [])
+    stamp = tuple((t._version, t.data_ptr()) for t in tensors)
+    hit = owner.__dict__.get('_folded')
+    if hit is None or hit[0] != stamp:
+        with torch.no_grad():
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            w = conv.weight * scale.view(-1, 1, 1, 1)
+            b = bn.bias - bn.running_mean * scale
+            if conv.bias is not None:
+                b = b + conv.bias * scale
+        hit = (stamp, w.contiguous(), b.contiguous())
+        owner.__dict__['_folded'] = hit
+    return hit[1], hit[2]
+
+
+class _Stem(nn.Sequential):
+    """``Sequential(conv1, bn1, relu, maxpool)`` of the reference (same keys).  Eval mode on the GPU: batch
+    norm folded into the convolution's weights and the max-pool taken before the ReLU (they commute), so
+    the ReLU runs on the pooled tensor -- an inference-only rewrite of stock PyTorch ops, no custom kernel."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        conv, bn, relu, pool = self[0], self[1], self[2], self[3]
+        if _eval_fold_ok(self, bn, x):
+            w, b = _folded_conv_bn(self, conv, bn)
+            return torch.relu_(pool(nn.functional.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)))
+        return pool(relu(bn(conv(x))))
+
+
+class _ConvBN(nn.Sequential):
+    """``Sequential(conv, bn)`` (same ``state_dict`` keys as the reference) that runs as ONE convolution
+    with the batch norm folded into its weights and bias in eval mode on the GPU."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        conv, bn = self[0], self[1]
+        if _eval_fold_ok(self, bn, x):
+            w, b = _folded_conv_bn(self, conv, bn)
+            return nn.functional.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return bn(conv(x))
+
+
 def _projection(in_planes: int, planes: int, stride: int, bias: bool) -> nn.Sequential:
     """Full-precision down-sampling shortcut (empty when shapes already agree)."""
     if stride == 1 and in_planes == planes:
         return nn.Sequential()
-    return nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride, bias=bias),
-                         nn.BatchNorm2d(planes))
+    return _ConvBN(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride, bias=bias),
+                   nn.BatchNorm2d(planes))
 
 
 def _qconv(x_quant, w_quant, cin, cout, clamp, mode, momentum, stride, bias):
@@ -137,7 +186,7 @@ class QResNet(nn.Module):
         else:
             raise ValueError(f"maxpool type {pool['type']} is not supported.")
         self.bn1 = nn.BatchNorm2d(width)
-        self.blocks = nn.ModuleList([nn.Sequential(self.conv1, self.bn1, nn.ReLU(inplace=True), self.maxpool)])
+        self.blocks = nn.ModuleList([_Stem(self.conv1, self.bn1, nn.ReLU(inplace=True), self.maxpool)])
 
         planes = width
         stages = [(layer1, width, num_blocks[0], 1), (layer2, 2 * width, num_blocks[1], 2),
