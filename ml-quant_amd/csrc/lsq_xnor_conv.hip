@@ -18,8 +18,12 @@
 
 #include "lsq_common.h"
 
+#include <cstdlib>
+
 namespace lsq {
 namespace {
+
+constexpr int kDefaultOT = 16;
 
 struct ConvArgs {
   const unsigned long long* xplanes;   // [KX][N][Gt][Hp][Wp]
@@ -164,10 +168,21 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
 }
 
 template <int KX>
-int launch_kx(const ConvArgs& a, int groups, hipStream_t st) {
+int launch_kx(ConvArgs a, int groups, hipStream_t st) {
   const long long total = (long long)a.N * a.Ho * a.Wo;
+  // out-channels per lane: the weight plane is padded to 16 per group; 32 needs og_pad % 32 == 0
+  // measured on MI355X: 8 channels per lane (59 VGPRs, 8 waves/SIMD) wins once the channel loop is long
+  // (C >= 256); 16 (78 VGPRs) wins for C = 64/128 where per-lane prologue/epilogue weigh more; 32 loses
+  int ot = a.Gg >= 4 ? 8 : kDefaultOT;
+#ifdef LSQ_TUNE
+  if (const char* e = getenv("LSQ_XNOR_OT")) ot = atoi(e);
+  if (ot == 32 && a.og_pad % 32) ot = 16;
+#endif
+  a.tiles_per_group = a.og_pad / ot;
   dim3 grid((unsigned)((total + 255) / 256), (unsigned)(groups * a.tiles_per_group));
-  hipLaunchKernelGGL((xnor_conv_kernel<KX, 16>), grid, dim3(256), 0, st, a);
+  if (ot == 32) hipLaunchKernelGGL((xnor_conv_kernel<KX, 32>), grid, dim3(256), 0, st, a);
+  else if (ot == 8) hipLaunchKernelGGL((xnor_conv_kernel<KX, 8>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((xnor_conv_kernel<KX, 16>), grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
