@@ -56,7 +56,9 @@ class _Stem(nn.Sequential):
         conv, bn, relu, pool = self[0], self[1], self[2], self[3]
         if _eval_fold_ok(self, bn, x):
             w, b = _folded_conv_bn(self, conv, bn)
-            return torch.relu_(pool(nn.functional.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)))
+            # a per-channel bias commutes with max-pooling too: add it on the pooled (4x smaller) tensor
+            y = pool(nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups))
+            return y.add_(b.view(1, -1, 1, 1)).relu_()
         return pool(relu(bn(conv(x))))
 
 
