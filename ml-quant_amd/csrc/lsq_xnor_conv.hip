@@ -41,14 +41,21 @@ struct ConvArgs {
   int relu;                            // epilogue: y = relu(conv + bias + res_pre) + res_post
   const float* res_pre;                // [N][O][Ho][Wo] or null
   const float* res_post;
+  int dbg_no_corr;                     // tuning builds only
   int tap_xoff[64];                    // (kh*dil_h)*Wp + kw*dil_w per tap
 };
 
 template <int KX, int OT>
 __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
-  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  // tap sums of this block's OT out-channels for the halo correction: whole-tap, per kernel row and per
+  // kernel column (inclusion-exclusion), so that a border pixel pays ~3 LDS reads per channel instead of
+  // up to KH*KW global reads -- every wave contains border pixels once rows are narrower than 64
+  __shared__ int s_ws[64][OT];
+  __shared__ int s_rs[8][OT], s_cs[8][OT];
+  const long long pix_raw = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)a.N * a.Ho * a.Wo;
-  if (pix >= total) return;
+  const bool pvalid = pix_raw < total;
+  const long long pix = pvalid ? pix_raw : total - 1;
   const int tile = blockIdx.y;
   const int grp = tile / a.tiles_per_group;
   const int t = tile - grp * a.tiles_per_group;
@@ -70,6 +77,27 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
   const unsigned long long* __restrict__ xp =
       a.xplanes + ((long long)n * a.Gt + (long long)grp * a.Gg) * HpWp + (long long)(ho * a.sh) * a.Wp + wo * a.sw;
   const unsigned long long* __restrict__ wbase = a.wbits + o_pad0;
+
+  {
+    const int ntap = a.KH * a.KW;
+    for (int i = threadIdx.x; i < ntap * OT; i += 256) {
+      const int tp = i / OT, o = i - tp * OT;
+      s_ws[tp][o] = o < o_valid ? a.wsum[(long long)(o0 + o) * ntap + tp] : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (a.KH + a.KW) * OT; i += 256) {
+      const int k = i / OT, o = i - k * OT;
+      int acc_s = 0;
+      if (k < a.KH) {
+        for (int kw = 0; kw < a.KW; ++kw) acc_s += s_ws[k * a.KW + kw][o];
+        s_rs[k][o] = acc_s;
+      } else {
+        for (int kh = 0; kh < a.KH; ++kh) acc_s += s_ws[kh * a.KW + (k - a.KH)][o];
+        s_cs[k - a.KH][o] = acc_s;
+      }
+    }
+    __syncthreads();
+  }
 
   // Loop over (channel word j, tap).  Everything address-like is a 32-bit word offset that advances by
   // a loop-invariant stride (the first version spent as many SALU instructions on 64-bit index math and
@@ -128,19 +156,36 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
 #pragma unroll
   for (int o = 0; o < OT; ++o) corr[o] = 0;
   const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
-  const bool border = hi0 < 0 || wi0 < 0 || hi0 + (a.KH - 1) * a.dh >= a.H || wi0 + (a.KW - 1) * a.dw >= a.W;
-  if (border) {
+  unsigned bad_h = 0, bad_w = 0;                   // bit k set: kernel row / column k falls outside the image
+  for (int kh = 0; kh < a.KH; ++kh) {
+    const int hi = hi0 + kh * a.dh;
+    bad_h |= (hi < 0 || hi >= a.H) ? 1u << kh : 0u;
+  }
+  for (int kw = 0; kw < a.KW; ++kw) {
+    const int wi = wi0 + kw * a.dw;
+    bad_w |= (wi < 0 || wi >= a.W) ? 1u << kw : 0u;
+  }
+  if ((bad_h | bad_w) && !a.dbg_no_corr) {
     for (int kh = 0; kh < a.KH; ++kh) {
-      for (int kw = 0; kw < a.KW; ++kw) {
-        const int hi = hi0 + kh * a.dh, wi = wi0 + kw * a.dw;
-        if (hi < 0 || hi >= a.H || wi < 0 || wi >= a.W) {
+      if ((bad_h >> kh) & 1u) {
 #pragma unroll
-          for (int o = 0; o < OT; ++o)
-            if (o < o_valid) corr[o] += a.wsum[(long long)(o0 + o) * taps + kh * a.KW + kw];
+        for (int o = 0; o < OT; ++o) corr[o] += s_rs[kh][o];
+        for (int kw = 0; kw < a.KW; ++kw) {
+          if ((bad_w >> kw) & 1u) {
+#pragma unroll
+            for (int o = 0; o < OT; ++o) corr[o] -= s_ws[kh * a.KW + kw][o];
+          }
         }
       }
     }
+    for (int kw = 0; kw < a.KW; ++kw) {
+      if ((bad_w >> kw) & 1u) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) corr[o] += s_cs[kw][o];
+      }
+    }
   }
+  if (!pvalid) return;
 
   float xs[KX];
 #pragma unroll
@@ -175,6 +220,7 @@ int launch_kx(ConvArgs a, int groups, hipStream_t st) {
   // (C >= 256); 16 (78 VGPRs) wins for C = 64/128 where per-lane prologue/epilogue weigh more; 32 loses
   int ot = a.Gg >= 4 ? 8 : kDefaultOT;
 #ifdef LSQ_TUNE
+  if (getenv("LSQ_XNOR_NOCORR")) a.dbg_no_corr = 1;
   if (const char* e = getenv("LSQ_XNOR_OT")) ot = atoi(e);
   if (ot == 32 && a.og_pad % 32) ot = 16;
 #endif
@@ -213,7 +259,7 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
   a.opad_total = g->groups * a.og_pad;
   a.tiles_per_group = a.og_pad / 16;
   a.xplane_words = lsq_act_plane_words(g);
-  if (g->KH * g->KW > 64 || a.xplane_words * kx >= (1ll << 31)) return LSQ_E_UNSUPPORTED;
+  if (g->KH * g->KW > 64 || g->KH > 8 || g->KW > 8 || a.xplane_words * kx >= (1ll << 31)) return LSQ_E_UNSUPPORTED;
   for (int kh = 0; kh < g->KH; ++kh)
     for (int kw = 0; kw < g->KW; ++kw) a.tap_xoff[kh * g->KW + kw] = kh * g->dil_h * a.Wp + kw * g->dil_w;
   a.bias = bias;
