@@ -65,22 +65,22 @@ def solve_row(row: np.ndarray, ternary: bool, skip: int = 1,
             cand_val.append(float(np.float32(extra)))
             cand_pos.append(-1)
 
-    def score(v1: float) -> float:
-        # closed form of cost^2 (minus nothing): sum (|a - v1| - v2)^2
-        k = int(np.searchsorted(a, v1, side='left'))         # elements < v1
-        below = prefix[k - 1] if k > 0 else 0.0
-        dev = (v1 * k - below) + ((total - below) - v1 * (n - k))   # sum |a - v1|
-        quad = sq_total - 2.0 * v1 * total + n * v1 * v1            # sum (a - v1)^2
+    def scores(v: np.ndarray) -> np.ndarray:
+        # closed form of cost^2 = sum (|a - v1| - v2)^2, vectorised over candidates
+        k = np.searchsorted(a, v, side='left')                  # elements < v1
+        below = np.where(k > 0, prefix[np.maximum(k, 1) - 1], 0.0)
+        dev = (v * k - below) + ((total - below) - v * (n - k))     # sum |a - v1|
+        quad = sq_total - 2.0 * v * total + n * v * v               # sum (a - v1)^2
         if ternary:
-            return quad - 2.0 * v1 * dev + n * v1 * v1
-        v2 = dev / n
-        return quad - n * v2 * v2
+            return quad - 2.0 * v * dev + n * v * v
+        return quad - dev * dev / n
 
     if not cand_val:
         best, costs = np.float32(0.0), []
     else:
-        costs = [score(v) for v in cand_val]
+        costs = scores(np.asarray(cand_val, dtype=np.float64))
         best = np.float32(cand_val[int(np.argmin(costs))])
+        costs = costs.tolist()
     if details is not None:
         details.update(sorted=a32, positions=cand_pos, values=cand_val, cost_sq=costs, n=n)
     return best

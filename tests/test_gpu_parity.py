@@ -191,6 +191,92 @@ def test_solver_hard_rows():
             assert np.array_equal(v12[0].cpu().numpy(), exact), (tag, ternary, v12[0].cpu().numpy(), exact)
 
 
+def _solver_diag(rows, skip, ternary):
+    """(v1, flagged level-1 bins, slots resolved by the block-level path, slots read straight from the row)."""
+    hip = _hip()
+    r = rows.shape[0]
+    v12, _ = hip.solve_rows(torch.from_numpy(rows).to(DEV), skip, ternary)
+    torch.cuda.synchronize()
+    ws_row = hip.lib().lsq_solver_workspace_bytes(1)
+    ws = hip.solver_workspace(r, DEV)[:r * ws_row].cpu().numpy().reshape(r, ws_row)
+    hdr = ws[:, :16].copy().view(np.uint32).reshape(r, 4)
+    return v12[0].cpu().numpy(), hdr[:, 0], hdr[:, 3] & 0xFFFF, hdr[:, 3] >> 16
+
+
+def test_solver_rare_paths_are_exercised():
+    """Rows built to force the paths ordinary data never takes: hundreds of flagged bins (level-1
+    re-scan, no LDS list), more than four runs of flagged bins (role-table gather), dense sub-bins
+    (block-level refinement), one bin larger than the LDS list (histogram straight from the row)."""
+    rs = np.random.RandomState(5)
+    # Pareto(2): half the tail mean equals the threshold everywhere -> every bin is a crossing bin
+    # built backwards so that a[i] = half the mean of everything above it holds at EVERY position:
+    # a[n-1-k] = V * prod_{c<=k} (2c-1)/(2c)  (ten binades at n = 1.5e6 -> more than 256 crossing bins)
+    n = 1_500_000
+    c = np.arange(1, n, dtype=np.float64)
+    q = np.concatenate([[1.0], np.cumprod((2 * c - 1) / (2 * c))])[::-1] * 1000.0
+    pareto = np.stack([q[rs.permutation(n)], q]).astype(np.float32)
+    v, tflag, slow, rowpass = _solver_diag(pareto, 1, True)
+    assert tflag.max() > 256, tflag
+    assert np.array_equal(v, E.solve_rows(pareto, True, 1))
+    small = (rs.pareto(2.0, (2, 60000)) + 1).astype(np.float32)
+    v, tflag, slow, rowpass = _solver_diag(small, 1, False)
+    assert np.array_equal(v, E.solve_rows(small, False, 1))
+    # five well separated clusters whose internal structure repeats: > 4 runs of flagged bins
+    base = np.abs(rs.standard_normal((3, 6000))).astype(np.float32)
+    multi = np.concatenate([base * s for s in (1.0, 37.0, 1400.0, 5.2e4, 2.0e6, 7.7e7)], axis=1)
+    for ternary in (False, True):
+        v, tflag, slow, rowpass = _solver_diag(multi, 1, ternary)
+        assert np.array_equal(v, E.solve_rows(multi, ternary, 1)), ternary
+    # a narrow band of 30000 distinct values inside one sub-bin range -> dense sub-bins (> 64 keys)
+    dense = (1.0 + np.arange(30000, dtype=np.float64) * 2.0 ** -22).astype(np.float32)[None, :].repeat(2, 0)
+    dense[1] = dense[1][::-1]
+    v, tflag, slow, rowpass = _solver_diag(dense, 1, False)
+    assert (slow + rowpass).max() >= 1, (slow, rowpass)
+    assert np.array_equal(v, E.solve_rows(dense, False, 1))
+    # 120000 keys in one level-1 bin (more than the LDS list holds), all different
+    big = (1.5 + rs.random_sample((1, 120000)) * 2.0 ** -8).astype(np.float32)
+    v, tflag, slow, rowpass = _solver_diag(big, 1, False)
+    assert rowpass.max() >= 1
+    assert np.array_equal(v, E.solve_rows(big, False, 1))
+
+
+@pytest.mark.parametrize('skip', [1, 2, 5])
+def test_act_quant_other_skips_and_tiny_shapes(skip):
+    """Sub-sampling strides other than the reference's default and degenerate geometries."""
+    for shape, pad in (((1, 1, 1, 1), (0, 0)), ((2, 1, 3, 5), (1, 1)), ((1, 65, 2, 2), (1, 0)), ((3, 64, 14, 14), (1, 1))):
+        x = detgen.normal(f'gpu.skip.{shape}', shape, scale=1.2)
+        planes, scales = run_act_quant(x, 2, 2, 2.0, 1, pad, skip=skip)
+        xc = x.clamp(-2, 2)
+        exact = E.solve_rows(xc.numpy(), False, skip)
+        assert np.array_equal(scales[0].numpy(), exact), (shape, skip)
+        v2 = P.quant_ls2(xc, scales[0])[1]
+        assert torch.allclose(scales[1], v2, rtol=2e-6, atol=1e-12)
+        for q, b in enumerate(planes_ref(xc, list(scales))):
+            assert np.array_equal(planes[q], pack_ref(b, 1, pad)), (shape, skip, q)
+
+
+def test_c_abi_argument_errors_on_device():
+    hip = _hip()
+    lib = hip.lib()
+    import ctypes
+    x = torch.zeros(2, 64, 4, 4, device=DEV)
+    g = hip.make_geom(2, 64, 4, 4, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+    planes = torch.zeros(2 * hip.act_plane_words(g), dtype=torch.int64, device=DEV)
+    scales = torch.zeros(2, 2, device=DEV)
+    # ls-2 without a workspace, with a short workspace, with a wrong plane count
+    assert lib.lsq_act_quant(x.data_ptr(), ctypes.byref(g), 2, 2, 3, 2.0, None, None, None, planes.data_ptr(),
+                             scales.data_ptr(), None, 0, None) == -1
+    ws = torch.zeros(64, dtype=torch.uint8, device=DEV)
+    assert lib.lsq_act_quant(x.data_ptr(), ctypes.byref(g), 2, 2, 3, 2.0, None, None, None, planes.data_ptr(),
+                             scales.data_ptr(), ws.data_ptr(), ws.numel(), None) == -5
+    assert lib.lsq_act_quant(x.data_ptr(), ctypes.byref(g), 2, 3, 3, 2.0, None, None, None, planes.data_ptr(),
+                             scales.data_ptr(), None, 0, None) == -3
+    assert lib.lsq_act_quant(x.data_ptr(), ctypes.byref(g), 9, 1, 3, 2.0, None, None, None, planes.data_ptr(),
+                             scales.data_ptr(), None, 0, None) == -3
+    # a sub-sampled row of 2^22 keys or more is refused, not silently mis-counted
+    assert lib.lsq_solve_rows(x.data_ptr(), 1, 1 << 23, 1, 0, -1.0, scales.data_ptr(), None, ws.data_ptr(), ws.numel(), None) == -4
+
+
 # ------------------------------------------------------------------------------------------------
 PAIRS = [('ls-1', 'ls-1'), ('ls-2', 'ls-1'), ('ls-T', 'ls-1'), ('gf-2', 'ls-1'),
          ('ls-2', 'ls-2'), ('ls-1', 'gf-2'), ('ls-T', 'ls-T')]
