@@ -166,11 +166,15 @@ __global__ __launch_bounds__(256) void signw_conv_kernel(SwArgs a) {
 constexpr int kKC = 32;                         // channels per K-chunk
 constexpr int kRowB = kKC * 2 + 16;             // LDS row pitch in bytes (64 data + 16 pad)
 constexpr int kBN = 128;                        // pixels per block
+#ifndef LSQ_SIGNW_LDS_BUFS
+#define LSQ_SIGNW_LDS_BUFS 1
+#endif
+constexpr int kLdsBufs = LSQ_SIGNW_LDS_BUFS;    // 2: one barrier per chunk; 1: two barriers, half the LDS, more blocks per CU
 
 template <int BM, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == kBN, "tile shape");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2][(BM + 2 * kBN) * kRowB];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBufs][(BM + 2 * kBN) * kRowB];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid - wm * WN;
   const int col = lane & 31, kh8 = lane >> 5;
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
   store_chunk(0);
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
+    const int buf = kLdsBufs == 2 ? (ch & 1) : 0;
     if (ch + 1 < nchunks) load_chunk(ch + 1);          // in flight during the MFMAs below
     const unsigned char* sA = smem[buf];
     const unsigned char* sBh = sA + BM * kRowB;
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bl[j].v, acc[i][j], 0, 0, 0);
         }
     }
-    if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+    if (kLdsBufs == 1) __syncthreads();          // everyone is done reading before the single buffer is rewritten
+    if (ch + 1 < nchunks) store_chunk(kLdsBufs == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 

@@ -38,6 +38,8 @@ class QLeNet5(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = F.max_pool2d(self.bn_conv1(F.relu(self.conv1(x))), kernel_size=2, stride=2)
-        x = F.max_pool2d(F.relu(self.conv2(self.bn_conv2(x))), kernel_size=2, stride=2)
+        # bn -> quantized conv -> relu: one fused call (on the HIP path the batch norm is folded into the
+        # quantizer's read and the ReLU into the conv epilogue; elsewhere it is the plain composition)
+        x = F.max_pool2d(self.conv2.fused_forward(x, self.bn_conv2, relu=True), kernel_size=2, stride=2)
         x = F.relu(self.fc1(x.reshape(-1, self.conv2_filters * 4 * 4)))
         return F.log_softmax(self.fc2(x), dim=1)
