@@ -56,9 +56,17 @@ class _Stem(nn.Sequential):
         conv, bn, relu, pool = self[0], self[1], self[2], self[3]
         if _eval_fold_ok(self, bn, x):
             w, b = _folded_conv_bn(self, conv, bn)
-            # a per-channel bias commutes with max-pooling too: add it on the pooled (4x smaller) tensor
-            y = pool(nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups))
-            return y.add_(b.view(1, -1, 1, 1)).relu_()
+            # a per-channel bias commutes with max-pooling too: add it on the pooled (4x smaller) tensor.
+            # MIOpen's 7x7 stride-2 convolution and the pooling are ~1.3x / ~1.9x faster in channels-last
+            # (measured, scripts/stem_bench.py); the bias add writes the NCHW tensor the quantizer reads.
+            hit = self.__dict__.get('_folded_cl')
+            if hit is None or hit[0] is not w:
+                hit = self.__dict__['_folded_cl'] = (w, w.contiguous(memory_format=torch.channels_last))
+            y = pool(nn.functional.conv2d(x.contiguous(memory_format=torch.channels_last), hit[1], None,
+                                          conv.stride, conv.padding, conv.dilation, conv.groups))
+            out = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+            torch.add(y, b.view(1, -1, 1, 1), out=out)
+            return out.relu_()
         return pool(relu(bn(conv(x))))
 
 
