@@ -1,1 +1,1 @@
-"""Small utilities (moving average)."""
+"""Small utilities (moving average, checkpoint files)."""

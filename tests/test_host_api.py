@@ -303,3 +303,43 @@ def test_config0_lenet_plumbing(golden, tag):
     with torch.no_grad():
         y = model(detgen.normal(tag + '.x', (64, 1, 28, 28)))
     assert y.shape == (64, 10) and torch.equal(y, g[tag + '_logp'])
+
+
+def test_checkpoint_files_in_the_reference_layout(golden, tmp_path):
+    """A ``checkpoint_<epoch>.pt`` in the reference's layout (utils/checkpoints.py:40-51) restores into a
+    fresh model, which then reproduces the reference's log-probs; latest / requested epoch lookup and the
+    error cases follow ``get_path_to_checkpoint`` (:107-136)."""
+    from quant.utils.checkpoints import get_path_to_checkpoint, log_checkpoints, restore_from_checkpoint
+    g, tag = golden('f7_lenet'), 'mnist_ls1'
+    src = QLeNet5(loss_fn=torch.nn.functional.nll_loss, **g.json(tag + '_arch'))
+    detgen.fill_module(src, seed=3)
+    with torch.no_grad():
+        src.conv2.w_approximate.v1.copy_(P.weight_scales(src.conv2.weight, 'ls-1')[0])
+    opt = torch.optim.SGD(src.parameters(), lr=0.1, momentum=0.9)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2)
+    with pytest.raises(ValueError):
+        (tmp_path / 'exp' / 'checkpoints').mkdir(parents=True)
+        get_path_to_checkpoint(tmp_path / 'exp')
+    log_checkpoints(tmp_path / 'exp' / 'checkpoints', src, opt, sched, 3)
+    log_checkpoints(tmp_path / 'exp' / 'checkpoints', nn.DataParallel(src), opt, sched, 11)
+    assert get_path_to_checkpoint(tmp_path / 'exp').endswith('checkpoint_11.pt')
+    assert get_path_to_checkpoint(tmp_path / 'exp', 3).endswith('checkpoint_3.pt')
+    with pytest.raises(ValueError):
+        get_path_to_checkpoint(tmp_path / 'exp', 4)
+    raw = torch.load(get_path_to_checkpoint(tmp_path / 'exp'))
+    assert set(raw) == {'epoch', 'model_state_dict', 'optimizer_state_dict', 'scheduler_state_dict'}
+    assert list(raw['model_state_dict']) == list(src.state_dict())            # no 'module.' prefix
+    dst = QLeNet5(loss_fn=torch.nn.functional.nll_loss, **g.json(tag + '_arch'))
+    dst.eval()
+    dst.conv2._hip_cache['stale'] = object()                                   # derived state must not survive
+    _, o2, s2, epoch = restore_from_checkpoint(dst, torch.optim.SGD(dst.parameters(), lr=0.5),
+                                               None, get_path_to_checkpoint(tmp_path / 'exp'),
+                                               torch.device('cpu'))
+    assert epoch == 11 and s2 is None and o2.param_groups[0]['lr'] == 0.1 and not dst.conv2._hip_cache
+    with torch.no_grad():
+        assert torch.equal(dst(detgen.normal(tag + '.x', (64, 1, 28, 28))), g[tag + '_logp'])
+    with pytest.raises(RuntimeError):
+        restore_from_checkpoint(QLeNet5(loss_fn=None, w_quant='ls-2'), None, None,
+                                get_path_to_checkpoint(tmp_path / 'exp'), torch.device('cpu'))
+    restore_from_checkpoint(QLeNet5(loss_fn=None, w_quant='ls-2'), None, None,
+                            get_path_to_checkpoint(tmp_path / 'exp'), torch.device('cpu'), strict_keys=False)
