@@ -6,14 +6,15 @@
 // Implicit GEMM, transposed so that stores are coalesced:  D[o][pixel] = sum_k S[o][k] * X[k][pixel],
 // k = (tap, channel).  v_mfma_f32_32x32x16_bf16: A = 32 out-channels x 16 channels of +-1 (exact in
 // bf16), B = 16 channels x 32 pixels of activations.  fp32 activations are split x = hi + lo with
-// hi = bf16 truncation of x and lo = bf16(x - hi): two MFMAs per tile, relative error <= 2^-16 per
-// product, fp32 accumulation -- inside the 1e-4 bound where single bf16 (2^-8) is not.
+// hi = bf16(x) and lo = bf16(x - hi): two MFMAs per tile, relative error <= 2^-18 per product, fp32
+// accumulation -- inside the 1e-4 bound where single bf16 (2^-9) is not.  Zero padding and channel
+// padding are exact (x = 0 contributes 0).
 //
-// One wave owns 32 consecutive output pixels x (32*OTW) output channels: each activation fragment is
-// loaded once (8 floats per lane, lanes = consecutive pixels => coalesced 128 B segments per channel)
-// and reused for OTW weight tiles and both halves of the split.  A weight fragment is ONE byte of the
-// packed sign plane per lane (8 consecutive channels of one out-channel), expanded to 8 bf16 with
-// three VALU ops per pair.  Zero padding and channel padding are exact (x = 0 contributes 0).
+// Two kernels.  signw_conv_patch (stride 1): the workgroup keeps, per 32-channel chunk, the whole input
+// patch its 128 output pixels touch in LDS (already batch-norm-folded, clamped and split), and all
+// KH*KW taps read their B fragments from it at shifted rows -- each input element is loaded and
+// converted once per workgroup instead of once per tap.  signw_conv_tiled (any stride): im2col staging
+// per (tap, chunk).
 
 #include "lsq_common.h"
 
@@ -46,116 +47,22 @@ union Frag {
   bf16x8 v;
 };
 
-// 8 sign bits (bit j = channel j) -> 8 bf16 values +1 / -1
-__device__ __forceinline__ bf16x8 expand_signs(unsigned byte) {
-  Frag f;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const unsigned b0 = (byte >> (2 * p)) & 1u, b1 = (byte >> (2 * p + 1)) & 1u;
-    f.u[p] = 0x3F803F80u | ((b0 ^ 1u) << 15) | ((b1 ^ 1u) << 31);
-  }
-  return f.v;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// x = hi + lo in bf16: hi = bf16(x) (v_cvt_pk_bf16_f32, round to nearest even), lo = bf16(x - hi).
+// x - hi is exact in fp32, so |x - hi - lo| <= 2^-18 |x|.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x0, x1};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const bf16x2 l = __builtin_convertvector(r, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
 }
-
-template <int OTW>
-__global__ __launch_bounds__(256) void signw_conv_kernel(SwArgs a) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int col = lane & 31, kh8 = lane >> 5;          // pixel / out-channel within the tile, k half
-  const long long total = (long long)a.N * a.Ho * a.Wo;
-  const long long pix = ((long long)blockIdx.x * 4 + wid) * 32 + col;
-  const bool pvalid = pix < total;
-  const int tile = blockIdx.y;
-  const int grp = tile / a.tiles_per_group;
-  const int t = tile - grp * a.tiles_per_group;
-  const int o_pad0 = grp * a.og_pad + t * (32 * OTW);
-  const int o0 = grp * a.og + t * (32 * OTW);
-  const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
-  const long long pc = pvalid ? pix : 0;
-  const int n = (int)(pc / HoWo);
-  const int r = (int)(pc - (long long)n * HoWo);
-  const int ho = r / a.Wo, wo = r - ho * a.Wo;
-  const float* xg = a.x + ((long long)n * a.C + (long long)grp * a.cg) * HW;
-
-  f32x16 acc[OTW];
-#pragma unroll
-  for (int i = 0; i < OTW; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-  for (int kh = 0; kh < a.KH; ++kh) {
-    for (int kw = 0; kw < a.KW; ++kw) {
-      const int hi = ho * a.sh - a.ph + kh * a.dh, wi = wo * a.sw - a.pw + kw * a.dw;
-      const bool inb = pvalid && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      const float* xp = xg + (long long)hi * a.W + wi;
-      const int tap = kh * a.KW + kw;
-      for (int c0 = 0; c0 < a.cg; c0 += 16) {
-        // B fragment: 8 channels of this lane's pixel
-        float xv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int c = c0 + 8 * kh8 + j;
-          float t = 0.f;
-          if (inb && c < a.cg) {
-            t = xp[(long long)c * HW];
-            if (a.pre_scale) t = fmaf(t, a.pre_scale[grp * a.cg + c], a.pre_shift[grp * a.cg + c]);
-            t = clamp_sym(t, a.alpha);
-          }
-          xv[j] = t;
-        }
-        Frag bhi, blo;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const unsigned x0 = __float_as_uint(xv[2 * p]), x1 = __float_as_uint(xv[2 * p + 1]);
-          const unsigned h0 = x0 & 0xFFFF0000u, h1 = x1 & 0xFFFF0000u;              // truncation to bf16
-          const unsigned l0 = __float_as_uint(xv[2 * p] - __uint_as_float(h0));     // exact in fp32
-          const unsigned l1 = __float_as_uint(xv[2 * p + 1] - __uint_as_float(h1));
-          const unsigned r0 = (l0 + 0x7FFFu + ((l0 >> 16) & 1u)) >> 16;             // round to nearest even
-          const unsigned r1 = (l1 + 0x7FFFu + ((l1 >> 16) & 1u)) & 0xFFFF0000u;
-          bhi.u[p] = (h0 >> 16) | h1;
-          blo.u[p] = r0 | r1;
-        }
-        // A fragments: one byte of the packed plane per lane and tile
-        const int g = c0 >> 6, byte_sel = ((c0 & 63) >> 3) + kh8;
-        const unsigned long long* wp = a.wbits + ((long long)tap * a.Gg + g) * a.opad_total + o_pad0 + col;
-#pragma unroll
-        for (int i = 0; i < OTW; ++i) {
-          // out-channel slots beyond the padded group width do not exist in the plane
-          const unsigned long long wv = (t * (32 * OTW) + 32 * i + col) < a.og_pad ? wp[32 * i] : 0ull;
-          const bf16x8 af = expand_signs((unsigned)(wv >> (8 * byte_sel)) & 0xFFu);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bhi.v, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, blo.v, acc[i], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  if (!pvalid) return;
-  float* yp = a.y + ((long long)n * a.O + o0) * HoWo + r;
-#pragma unroll
-  for (int i = 0; i < OTW; ++i) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int ol = 32 * i + (j & 3) + 8 * (j >> 2) + 4 * kh8;     // C/D layout of the 32x32 MFMA
-      if (t * (32 * OTW) + ol < a.og) {
-        const int o = o0 + ol;
-        const float v = acc[i][j] * a.wscale[o];
-        const float base = a.accumulate ? yp[(long long)ol * HoWo] : (a.bias ? a.bias[o] : 0.f);
-        float out = base + v;
-        if (a.final_pass) {
-          const long long yi = ((long long)n * a.O + o) * HoWo + r;
-          if (a.res_pre) out += a.res_pre[yi];
-          if (a.relu) out = fmaxf(out, 0.f);
-          if (a.res_post) out += a.res_post[yi];
-        }
-        yp[(long long)ol * HoWo] = out;
-      }
-    }
-  }
-}
-
 
 // ---------------------------------------------------------------------------------------------
-// Tiled version: a 256-thread workgroup computes BM out-channels x 128 pixels.  Per K-chunk (one tap,
+// Tiled (im2col) version: a 256-thread workgroup computes BM out-channels x 128 pixels.  Per K-chunk (one tap,
 // 32 channels) the block stages into LDS, ONCE for its four waves, (a) the +-1 weight fragment expanded
 // from 4 bytes of the packed plane per out-channel and (b) the activation chunk already clamped /
 // batch-norm-folded and split into bf16 hi and lo, both as [row][32 k] with a 16-byte row pad so that
@@ -169,7 +76,43 @@ constexpr int kBN = 128;                        // pixels per block
 #ifndef LSQ_SIGNW_LDS_BUFS
 #define LSQ_SIGNW_LDS_BUFS 1
 #endif
+constexpr int kMaxItems = 6;                     // patch kernel: at most 6 * 64 = 384 patch entries
 constexpr int kLdsBufs = LSQ_SIGNW_LDS_BUFS;    // 2: one barrier per chunk; 1: two barriers, half the LDS, more blocks per CU
+
+// Epilogue shared by both kernels: lane = pixel column, registers = out-channel rows (coalesced 128-byte
+// stores); y = relu(u * acc + bias|y + res_pre) + res_post on the last weight plane.
+template <int BM, int TM, int TN>
+__device__ __forceinline__ void store_tiles(const SwArgs& a, const f32x16 (&acc)[TM][TN], int t, int o0,
+                                            int wm, int wn, int col, int kh8) {
+  const int HoWo = a.Ho * a.Wo;
+  const long long total = (long long)a.N * HoWo;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const long long pix = (long long)blockIdx.x * kBN + (wn * TN + j) * 32 + col;
+    if (pix >= total) continue;
+    const int n = (int)(pix / HoWo);
+    const int r = (int)(pix - (long long)n * HoWo);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ol = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh8;   // C/D layout of the 32x32 MFMA
+        if (t * BM + ol < a.og) {
+          const int o = o0 + ol;
+          const long long yi = ((long long)n * a.O + o) * HoWo + r;
+          const float v = acc[i][j][q] * a.wscale[o];
+          float out = (a.accumulate ? a.y[yi] : (a.bias ? a.bias[o] : 0.f)) + v;
+          if (a.final_pass) {
+            if (a.res_pre) out += a.res_pre[yi];
+            if (a.relu) out = fmaxf(out, 0.f);
+            if (a.res_post) out += a.res_post[yi];
+          }
+          a.y[yi] = out;
+        }
+      }
+    }
+  }
+}
 
 template <int BM, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
@@ -243,17 +186,11 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
     unsigned char* sA = smem[buf];
     unsigned char* sBh = sA + BM * kRowB;
     unsigned char* sBl = sBh + kBN * kRowB;
-    // activations -> bf16 hi (truncation) and lo (rounded remainder), 16 values = 32 bytes each
+    // activations -> bf16 hi and lo = bf16(x - hi) (x - hi is exact in fp32; |x - hi - lo| <= 2^-18 |x|),
+    // 16 values = 32 bytes each
     unsigned hi[8], lo[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const unsigned x0 = __float_as_uint(xr[2 * p]), x1 = __float_as_uint(xr[2 * p + 1]);
-      const unsigned h0 = x0 & 0xFFFF0000u, h1 = x1 & 0xFFFF0000u;
-      const unsigned l0 = __float_as_uint(xr[2 * p] - __uint_as_float(h0));
-      const unsigned l1 = __float_as_uint(xr[2 * p + 1] - __uint_as_float(h1));
-      hi[p] = (h0 >> 16) | h1;
-      lo[p] = ((l0 + 0x7FFFu + ((l0 >> 16) & 1u)) >> 16) | ((l1 + 0x7FFFu + ((l1 >> 16) & 1u)) & 0xFFFF0000u);
-    }
+    for (int p = 0; p < 8; ++p) split_pair(xr[2 * p], xr[2 * p + 1], hi[p], lo[p]);
     uint4* dh = reinterpret_cast<uint4*>(sBh + sp * kRowB + skh * 32);
     uint4* dl = reinterpret_cast<uint4*>(sBl + sp * kRowB + skh * 32);
     dh[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
@@ -315,33 +252,234 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane = pixel column, registers = out-channel rows (coalesced 128-byte stores)
+  store_tiles<BM, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch version (stride 1, any padding / dilation).  Padded coordinates hp = hi + pad_h, wp = wi + pad_w
+// and the linear index L = (n*Hp + hp)*Wp + wp: output pixel (n, ho, wo) and tap (kh, kw) read
+// L = B + T with B = (n*Hp + ho)*Wp + wo and T = kh*dil_h*Wp + kw*dil_w.  The 128 consecutive output
+// pixels of a workgroup therefore touch the contiguous range [B_first, B_last + T_max] of L -- the patch,
+// at most PLr entries (host-side bound, multiple of 64).  Per 32-channel chunk the workgroup
+//   1. loads the patch once (lanes = consecutive entries = consecutive addresses of one channel: coalesced),
+//      applies the folded batch norm and clamp, splits into bf16 hi / lo and writes LDS rows
+//      [entry][32 channels] (80-byte pitch: conflict-free 16-byte fragment reads);
+//   2. loops over the taps: B fragments are the rows (entry of the lane's pixel + T); A fragments are
+//      expanded in registers from bytes of the packed weight plane (no weight LDS, no per-tap barrier:
+//      two barriers per chunk).
+// Global traffic and conversion work per workgroup drop by ~KH*KW / (1 + halo) against the im2col kernel.
+template <int BM, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp, int PLr) {
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == kBN, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  unsigned char* sPh = dsm;                              // [PLr][kRowB] bf16 hi
+  unsigned char* sPl = sPh + PLr * kRowB;                // [PLr][kRowB] bf16 lo
+  float* sPre = reinterpret_cast<float*>(sPl + PLr * kRowB);   // [2][cchunks * 32] folded batch norm of this group
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const int col = lane & 31, kh8 = lane >> 5;
+  const int tile = blockIdx.y;
+  const int grp = tile / a.tiles_per_group;
+  const int t = tile - grp * a.tiles_per_group;
+  const int o_pad0 = grp * a.og_pad + t * BM;
+  const int o0 = grp * a.og + t * BM;
+  const int HoWo = a.Ho * a.Wo, HW = a.H * a.W, HpWp = Hp * Wp;
+  const int total = a.N * HoWo;
+  const int taps = a.KH * a.KW;
+  const int cchunks = (a.cg + kKC - 1) / kKC;
+  const bool ragged = (a.cg % kKC) != 0;
+  const int npre = cchunks * kKC;
+
+  // 32-bit index math throughout: the host takes this kernel only when N*Hp*Wp and N*C*H*W fit in 31 bits
+  auto base_of = [&](int p) {
+    const int n = p / HoWo;
+    const int r = p - n * HoWo;
+    const int ho = r / a.Wo;
+    return (n * Hp + ho) * Wp + (r - ho * a.Wo);
+  };
+  const int p0 = blockIdx.x * kBN;
+  const int bmin = base_of(p0);
+  int ep[TN];                                            // LDS byte offset of this lane's pixel row, per column tile
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const long long pix = (long long)blockIdx.x * kBN + (wn * TN + j) * 32 + col;
-    if (pix >= total) continue;
-    const int n = (int)(pix / HoWo);
-    const int r = (int)(pix - (long long)n * HoWo);
+    const int pix = p0 + (wn * TN + j) * 32 + col;
+    ep[j] = (pix < total ? (base_of(pix) - bmin) * kRowB : 0) + kh8 * 16;
+  }
+  const float* xg = a.x + (long long)grp * a.cg * HW;
+
+  // Weights never touch LDS: an A fragment (out-channel row = lane & 31, 8 channels) is ONE byte of the
+  // packed plane.  Per chunk each lane loads the words of its TM rows for a group of taps (issued before
+  // the patch staging, so their latency hides behind it), keeps the two bytes it needs (k-steps 0 / 1)
+  // and expands them to +-1 bf16 on the VALU, which is otherwise idle next to the MFMAs.
+  constexpr int kTapGroup = 9;
+  const unsigned long long* wrow[TM];
+  bool wrow_ok[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i) {
+    const int ol = (wm * TM + i) * 32 + col;
+    wrow_ok[i] = t * BM + ol < a.og_pad;
+    wrow[i] = a.wbits + o_pad0 + (wrow_ok[i] ? ol : 0);
+  }
+  unsigned wraw[kTapGroup][TM];                          // the 32 sign bits of (row, tap, chunk) as loaded
+  unsigned wpk[kTapGroup][TM];                           // byte 0: k-step 0, byte 1: k-step 1 of this lane's octet
+  auto issue_wloads = [&](unsigned (&dst)[kTapGroup][TM], int tg, int cc) {
+    const int c0 = cc * kKC;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int ol = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh8;
-        if (t * BM + ol < a.og) {
-          const int o = o0 + ol;
-          const long long yi = ((long long)n * a.O + o) * HoWo + r;
-          const float v = acc[i][j][q] * a.wscale[o];
-          float out = (a.accumulate ? a.y[yi] : (a.bias ? a.bias[o] : 0.f)) + v;
-          if (a.final_pass) {
-            if (a.res_pre) out += a.res_pre[yi];
-            if (a.relu) out = fmaxf(out, 0.f);
-            if (a.res_post) out += a.res_post[yi];
-          }
-          a.y[yi] = out;
+    for (int tt = 0; tt < kTapGroup; ++tt) {
+      const int tap = min(tg + tt, taps - 1);
+      const int word = (tap * a.Gg + (c0 >> 6)) * a.opad_total;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        dst[tt][i] = reinterpret_cast<const unsigned*>(wrow[i] + word)[(c0 >> 5) & 1];
+    }
+  };
+  auto pack_w = [&](const unsigned (&src)[kTapGroup][TM]) {
+#pragma unroll
+    for (int tt = 0; tt < kTapGroup; ++tt)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned v = wrow_ok[i] ? src[tt][i] >> (kh8 * 8) : 0u;
+        wpk[tt][i] = (v & 0xFFu) | ((v >> 8) & 0xFF00u);
+      }
+  };
+  // 8 sign bits -> 8 bf16 +-1 (bit set = +1): 0x3F80 with the sign bit taken from the inverted bit
+  auto expand = [&](unsigned byte, Frag& f) {
+    const unsigned nb = ~byte;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      f.u[q] = 0x3F803F80u | ((nb << (15 - 2 * q)) & 0x8000u) | ((nb << (30 - 2 * q)) & 0x80000000u);
+  };
+
+  // patch staging: item = (entry, channel octet), PLr / 64 <= kMaxItems items per thread; the octet is
+  // uniform per wave (PLr % 64 == 0).  The 8 loads of every item of chunk cc+1 are issued before the MFMA
+  // loop of chunk cc and consumed after it: one memory latency per chunk, hidden behind the matrix work.
+  const int n_items = PLr >> 6;
+  int it_off[kMaxItems], it_dst[kMaxItems], it_oct[kMaxItems];
+#pragma unroll
+  for (int u = 0; u < kMaxItems; ++u) {
+    const int i = tid + 256 * u;
+    const int oct = (i >= PLr) + (i >= 2 * PLr) + (i >= 3 * PLr);
+    const int e = i - oct * PLr;
+    const int L = bmin + e;
+    const int n = L / HpWp;
+    const int rem = L - n * HpWp;
+    const int hp = rem / Wp;
+    const int hi = hp - a.ph, wi = rem - hp * Wp - a.pw;
+    const bool inside = u < n_items && n < a.N && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+    it_off[u] = inside ? n * a.C * HW + hi * a.W + wi : -1;
+    it_dst[u] = e * kRowB + oct * 16;
+    it_oct[u] = oct;
+  }
+  float raw[kMaxItems][8];
+  auto issue_loads = [&](int cc) {
+    // halo / padded channels read a valid dummy address and are zeroed at conversion
+#pragma unroll
+    for (int u = 0; u < kMaxItems; ++u) {
+      if (u < n_items) {
+        const int c0 = cc * kKC + it_oct[u] * 8;
+        const float* xp = xg + (it_off[u] < 0 ? 0 : it_off[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = ragged ? min(c0 + j, a.cg - 1) : c0 + j;
+          raw[u][j] = xp[c * HW];
         }
       }
     }
+  };
+  auto convert_store = [&](int cc) {
+#pragma unroll
+    for (int u = 0; u < kMaxItems; ++u) {
+      if (u < n_items) {
+        const int c0 = cc * kKC + it_oct[u] * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = raw[u][j];
+        if (a.pre_scale) {                               // wave-uniform addresses: broadcast LDS reads
+          const float4* ps = reinterpret_cast<const float4*>(sPre + c0);
+          const float4* pb = reinterpret_cast<const float4*>(sPre + npre + c0);
+          const float4 s0 = ps[0], s1 = ps[1], b0 = pb[0], b1 = pb[1];
+          v[0] = fmaf(v[0], s0.x, b0.x); v[1] = fmaf(v[1], s0.y, b0.y);
+          v[2] = fmaf(v[2], s0.z, b0.z); v[3] = fmaf(v[3], s0.w, b0.w);
+          v[4] = fmaf(v[4], s1.x, b1.x); v[5] = fmaf(v[5], s1.y, b1.y);
+          v[6] = fmaf(v[6], s1.z, b1.z); v[7] = fmaf(v[7], s1.w, b1.w);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = (it_off[u] >= 0 && (!ragged || c0 + j < a.cg)) ? clamp_sym(v[j], a.alpha) : 0.f;
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+        *reinterpret_cast<uint4*>(sPh + it_dst[u]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(sPl + it_dst[u]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  issue_loads(0);
+  issue_wloads(wraw, 0, 0);
+  if (a.pre_scale) {
+    for (int c = tid; c < npre; c += 256) {
+      const int cs = grp * a.cg + min(c, a.cg - 1);
+      sPre[c] = a.pre_scale[cs];
+      sPre[npre + c] = a.pre_shift[cs];
+    }
+    __syncthreads();
   }
+  for (int cc = 0; cc < cchunks; ++cc) {
+    convert_store(cc);
+    pack_w(wraw);
+    __syncthreads();                                     // patch of this chunk visible
+    if (cc + 1 < cchunks) {                              // next chunk's loads fly during the MFMAs below
+      issue_loads(cc + 1);
+      issue_wloads(wraw, 0, cc + 1);
+    }
+    int kh = 0, kw = 0;
+    for (int tg = 0; tg < taps; tg += kTapGroup) {
+      if (tg) {                                          // more than 9 taps: later groups are loaded in place
+        unsigned wtmp[kTapGroup][TM];                    // (wraw already holds the next chunk's first group)
+        issue_wloads(wtmp, tg, cc);
+        pack_w(wtmp);
+      }
+#pragma unroll
+      for (int tt = 0; tt < kTapGroup; ++tt) {
+        if (tg + tt < taps) {
+          const int toff = (kh * a.dh * Wp + kw * a.dw) * kRowB;
+#pragma unroll
+          for (int ks = 0; ks < kKC / 16; ++ks) {
+            Frag af[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int row = ep[j] + toff + ks * 32;
+              const uint4 vh = *reinterpret_cast<const uint4*>(sPh + row);
+              const uint4 vl = *reinterpret_cast<const uint4*>(sPl + row);
+              bh[j].u[0] = vh.x; bh[j].u[1] = vh.y; bh[j].u[2] = vh.z; bh[j].u[3] = vh.w;
+              bl[j].u[0] = vl.x; bl[j].u[1] = vl.y; bl[j].u[2] = vl.z; bl[j].u[3] = vl.w;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) expand(wpk[tt][i] >> (8 * ks), af[i]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+              }
+          }
+          if (++kw == a.KW) { kw = 0; ++kh; }
+        }
+      }
+    }
+    __syncthreads();                                     // every wave is done reading before the patch is rewritten
+  }
+  store_tiles<BM, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
 }
 
 }  // namespace
@@ -378,14 +516,41 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
   const bool wide = a.og > 64;
   const int bm = wide ? 128 : 64;
   a.tiles_per_group = (a.og + bm - 1) / bm;
+  // stride-1 layers whose 128-pixel input patch fits LDS twice per CU take the patch kernel
+  const int Hp = g->H + 2 * g->pad_h, Wp = g->W + 2 * g->pad_w;
+  const long long patch = 128 + (127 / Wo + 1) * (long long)(Wp - Wo) + (127 / (Ho * Wo) + 1) * (long long)(Hp - Ho) * Wp +
+                          (long long)(g->KH - 1) * g->dil_h * Wp + (long long)(g->KW - 1) * g->dil_w;
+  const int PLr = (int)((patch + 63) / 64 * 64);
+  const int cg_pad = (a.cg + kKC - 1) / kKC * kKC;
+  const size_t patch_lds = (size_t)2 * PLr * kRowB + (pre_scale ? (size_t)2 * cg_pad * 4 : 0);
+  bool use_patch = g->stride_h == 1 && g->stride_w == 1 && PLr <= 64 * kMaxItems && patch_lds <= 80 * 1024 &&
+                   (long long)g->N * g->C * g->H * g->W < (1ll << 31) && (long long)g->N * Hp * Wp + PLr < (1ll << 31);
+#ifdef LSQ_TUNE
+  if (getenv("LSQ_SIGNW_NOPATCH")) use_patch = false;
+#endif
+  if (use_patch) {
+    static bool attr_done = false;       // benign race: the attribute is idempotent
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)signw_conv_patch<128, 2, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+          hipFuncSetAttribute((const void*)signw_conv_patch<64, 1, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+        return (int)hipGetLastError();
+      attr_done = true;
+    }
+  }
   for (int q = 0; q < kw_planes; ++q) {
     a.wbits = (const unsigned long long*)wbits + (long long)q * wplane_words;
     a.wscale = wscales + (long long)q * g->O;
     a.accumulate = q ? 1 : 0;
     a.final_pass = q == kw_planes - 1 ? 1 : 0;
     dim3 grid((unsigned)((total + kBN - 1) / kBN), (unsigned)(g->groups * a.tiles_per_group));
-    if (wide) hipLaunchKernelGGL((signw_conv_tiled<128, 2, 2, 2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((signw_conv_tiled<64, 1, 4, 2, 1>), grid, dim3(256), 0, st, a);
+    if (use_patch) {
+      if (wide) hipLaunchKernelGGL((signw_conv_patch<128, 2, 2, 2, 2>), grid, dim3(256), patch_lds, st, a, Hp, Wp, PLr);
+      else hipLaunchKernelGGL((signw_conv_patch<64, 1, 4, 2, 1>), grid, dim3(256), patch_lds, st, a, Hp, Wp, PLr);
+    } else if (wide) {
+      hipLaunchKernelGGL((signw_conv_tiled<128, 2, 2, 2, 2>), grid, dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((signw_conv_tiled<64, 1, 4, 2, 1>), grid, dim3(256), 0, st, a);
+    }
     if (int e = (int)hipGetLastError()) return e;
   }
   return LSQ_OK;

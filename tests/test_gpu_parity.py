@@ -421,6 +421,37 @@ def test_fp_activation_sign_weight_conv_mfma(golden, ws):
     assert rel_err(y, P.quant_conv2d(xw, w, b, 'fp', 'ls-1', wsc, None, 1, 1, 1, 2)) <= TOL
 
 
+
+@pytest.mark.parametrize('shape, cout, k, pad, dil, stride, groups', [
+    ((3, 64, 56, 56), 64, 3, 1, 1, 1, 1),     # LDS-patch kernel, workgroups crossing image rows and images
+    ((2, 40, 30, 30), 72, 3, 2, 2, 1, 1),     # patch kernel with dilation 2, ragged channel chunk, 72 out-channels
+    ((5, 32, 7, 7), 160, 3, 1, 1, 1, 1),      # several images per workgroup, 128-row tiles
+    ((2, 16, 20, 9), 24, (5, 2), (0, 1), 1, 1, 2),   # asymmetric kernel / padding, groups
+    ((1, 32, 10, 150), 32, 3, 1, 1, 1, 1),    # patch too long for LDS -> im2col kernel
+    ((2, 32, 31, 31), 48, 3, 1, 1, 2, 1),     # stride 2 -> im2col kernel
+])
+def test_fp_activation_conv_kernel_selection_geometries(shape, cout, k, pad, dil, stride, groups):
+    """Both MFMA kernels (stride-1 LDS-resident patch, im2col tiles) against the oracle on geometries that
+    exercise row / image wrap inside a workgroup, dilation, ragged channel chunks and the fall-back."""
+    from quant.binary.binary_conv import QuantConv2d
+    kk = (k, k) if isinstance(k, int) else k
+    x = detgen.normal(f'gpu.fpsel.x{shape}', shape, scale=1.5)
+    w = detgen.normal(f'gpu.fpsel.w{shape}', (cout, shape[1] // groups) + kk, scale=0.05)
+    b = detgen.normal(f'gpu.fpsel.b{shape}', (cout,), scale=0.1)
+    wsc = P.weight_scales(w, 'ls-1')
+    clamp = {'kind': 'symmetric', 'alpha': 2}
+    conv = QuantConv2d('fp', 'ls-1', shape[1], cout, k, clamp, stride=stride, padding=pad, dilation=dil, groups=groups)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(b)
+        conv.w_approximate.v1.copy_(wsc[0])
+    conv.eval().to(DEV)
+    with torch.no_grad():
+        y = conv(x.to(DEV)).cpu()
+    ref = P.quant_conv2d(x, w, b, 'fp', 'ls-1', wsc, clamp, stride, pad, dil, groups)
+    assert y.shape == ref.shape and rel_err(y, ref) <= TOL, rel_err(y, ref)
+
+
 def test_config0_lenet_and_fp_act_resnet_on_gpu(golden):
     """BASELINE configs[0] (LeNet, ls-1 weights, fp activations) and configs[3] (ResNet-18 ls-1w / fp-a)
     end to end on the GPU against the reference's outputs."""
