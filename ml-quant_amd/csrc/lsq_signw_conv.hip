@@ -49,6 +49,7 @@ union Frag {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 // x = hi + lo in bf16: hi = bf16(x) (v_cvt_pk_bf16_f32, round to nearest even), lo = bf16(x - hi).
 // x - hi is exact in fp32, so |x - hi - lo| <= 2^-18 |x|.
@@ -76,38 +77,70 @@ constexpr int kBN = 128;                        // pixels per block
 #ifndef LSQ_SIGNW_LDS_BUFS
 #define LSQ_SIGNW_LDS_BUFS 1
 #endif
-constexpr int kMaxItems = 6;                     // patch kernel: at most 6 * 64 = 384 patch entries
 constexpr int kLdsBufs = LSQ_SIGNW_LDS_BUFS;    // 2: one barrier per chunk; 1: two barriers, half the LDS, more blocks per CU
 
 // Epilogue shared by both kernels: lane = pixel column, registers = out-channel rows (coalesced 128-byte
-// stores); y = relu(u * acc + bias|y + res_pre) + res_post on the last weight plane.
-template <int BM, int TM, int TN>
+// stores); y = relu(u * acc + bias|y + res_pre) + res_post on the last weight plane.  Off = unsigned when
+// the host has checked 4*N*O*Ho*Wo < 2^32 (one vector add per output address), else size_t.
+template <typename Off, int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void store_tiles(const SwArgs& a, const f32x16 (&acc)[TM][TN], int t, int o0,
-                                            int wm, int wn, int col, int kh8) {
+                                              int wm, int wn, int col, int kh8) {
   const int HoWo = a.Ho * a.Wo;
   const long long total = (long long)a.N * HoWo;
+  Off pbase[TN];                                       // byte offset of (n, out-channel o0 + 4*kh8, pixel)
+  bool pok[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const long long pix = (long long)blockIdx.x * kBN + (wn * TN + j) * 32 + col;
-    if (pix >= total) continue;
-    const int n = (int)(pix / HoWo);
-    const int r = (int)(pix - (long long)n * HoWo);
+    const long long pix = (long long)blockIdx.x * BN + (wn * TN + j) * 32 + col;
+    pok[j] = pix < total;
+    const int n = pok[j] ? (int)(pix / HoWo) : 0;
+    const int r = pok[j] ? (int)(pix - (long long)n * HoWo) : 0;
+    pbase[j] = (Off)4 * ((Off)(n * a.O + o0 + 4 * kh8) * (Off)HoWo + (Off)r);
+  }
+  char* yb = reinterpret_cast<char*>(a.y);
+  const char* rpre = reinterpret_cast<const char*>(a.res_pre);
+  const char* rpost = reinterpret_cast<const char*>(a.res_post);
+  const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int ol = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh8;   // C/D layout of the 32x32 MFMA
-        if (t * BM + ol < a.og) {
-          const int o = o0 + ol;
-          const long long yi = ((long long)n * a.O + o) * HoWo + r;
-          const float v = acc[i][j][q] * a.wscale[o];
-          float out = (a.accumulate ? a.y[yi] : (a.bias ? a.bias[o] : 0.f)) + v;
+    for (int qh = 0; qh < 2; ++qh) {
+      // batch of 8 out-channel rows x TN pixel tiles: every load of the batch (previous partial sum,
+      // residuals, scale, bias) is issued before the first use -- a load consumed right after it is issued
+      // costs one memory latency per output
+      float ws[8], bs[8], prev[8][TN], r1[8][TN], r2[8][TN];
+      Off yo[8][TN];
+      bool ok[8][TN];
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        const int q = qh * 8 + qq;
+        const int olu = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2);      // wave-uniform part of the row
+        const int ol = olu + 4 * kh8;                                     // C/D layout of the 32x32 MFMA
+        const bool rok = t * BM + ol < a.og;
+        const int o = o0 + (rok ? ol : 0);
+        ws[qq] = a.wscale[o];
+        bs[qq] = (!a.accumulate && a.bias) ? a.bias[o] : 0.f;
+        const Off rowoff = (Off)4 * (Off)olu * (Off)HoWo;                 // scalar
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          ok[qq][j] = rok && pok[j];
+          yo[qq][j] = ok[qq][j] ? pbase[j] + rowoff : (Off)0;
+          prev[qq][j] = a.accumulate ? *reinterpret_cast<const float*>(yb + yo[qq][j]) : 0.f;
+          r1[qq][j] = want_pre ? *reinterpret_cast<const float*>(rpre + yo[qq][j]) : 0.f;
+          r2[qq][j] = want_post ? *reinterpret_cast<const float*>(rpost + yo[qq][j]) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float out = (a.accumulate ? prev[qq][j] : bs[qq]) + acc[i][j][qh * 8 + qq] * ws[qq];
           if (a.final_pass) {
-            if (a.res_pre) out += a.res_pre[yi];
+            out += r1[qq][j];
             if (a.relu) out = fmaxf(out, 0.f);
-            if (a.res_post) out += a.res_post[yi];
+            out += r2[qq][j];
           }
-          a.y[yi] = out;
+          if (ok[qq][j]) *reinterpret_cast<float*>(yb + yo[qq][j]) = out;
         }
       }
     }
@@ -252,29 +285,47 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
     __syncthreads();
   }
 
-  store_tiles<BM, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
+  store_tiles<size_t, BM, kBN, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Patch version (stride 1, any padding / dilation).  Padded coordinates hp = hi + pad_h, wp = wi + pad_w
 // and the linear index L = (n*Hp + hp)*Wp + wp: output pixel (n, ho, wo) and tap (kh, kw) read
-// L = B + T with B = (n*Hp + ho)*Wp + wo and T = kh*dil_h*Wp + kw*dil_w.  The 128 consecutive output
+// L = B + T with B = (n*Hp + ho)*Wp + wo and T = kh*dil_h*Wp + kw*dil_w.  The BN consecutive output
 // pixels of a workgroup therefore touch the contiguous range [B_first, B_last + T_max] of L -- the patch,
-// at most PLr entries (host-side bound, multiple of 64).  Per 32-channel chunk the workgroup
-//   1. loads the patch once (lanes = consecutive entries = consecutive addresses of one channel: coalesced),
-//      applies the folded batch norm and clamp, splits into bf16 hi / lo and writes LDS rows
-//      [entry][32 channels] (80-byte pitch: conflict-free 16-byte fragment reads);
-//   2. loops over the taps: B fragments are the rows (entry of the lane's pixel + T); A fragments are
-//      expanded in registers from bytes of the packed weight plane (no weight LDS, no per-tap barrier:
-//      two barriers per chunk).
-// Global traffic and conversion work per workgroup drop by ~KH*KW / (1 + halo) against the im2col kernel.
-template <int BM, int WM, int WN, int TM, int TN>
+// at most PLr <= 512 entries (host-side bound, multiple of 128).  Per 16-channel chunk (one MFMA k-step)
+// the workgroup
+//   1. converts the patch once: lanes = consecutive entries = consecutive addresses of one channel
+//      (coalesced), folded batch norm + clamp + bf16 hi / lo split, LDS rows [entry][16 channels] of 32
+//      bytes in a hi and a lo plane;
+//   2. expands the +-1 weights of up to 9 taps x BM out-channels x 16 channels from the packed plane
+//      into LDS rows of 32 bytes, cooperatively (each 16-bit piece once per workgroup);
+//   3. runs the taps back to back: A fragments at compile-time LDS offsets, B fragments at per-lane
+//      addresses (entry of the lane's pixel + T) computed once per workgroup -- no address arithmetic,
+//      no barrier and no global access inside the tap loop.
+// The global loads of chunk i+1 (activations and weight words) are issued right before the tap loop of
+// chunk i and consumed after it.  Rows have no padding: the two 16-byte halves of row r are swapped when
+// bit 3 of r is set, which makes any 16 consecutive rows hit 16 distinct 4-bank groups.
+// Each wave owns a 64 x 64 tile (2 x 2 MFMA tiles): 16 MFMAs per tap against 6 fragment reads.
+constexpr int kPC = 16;                          // channels per chunk
+constexpr int kPRow = 32;                        // bytes per LDS row (16 bf16)
+constexpr int kPMaxEntries = 512;                // patch entries the LDS planes hold
+constexpr int kPlane = kPMaxEntries * kPRow;     // lo plane follows the hi plane at this offset
+constexpr int kTapGroup = 9;                     // taps whose weights are resident at a time
+constexpr int kMaxPre = 512;                     // channels per group the folded-batch-norm table holds
+
+__device__ __forceinline__ int swz(int row, int half) { return row * kPRow + ((half ^ ((row >> 3) & 1)) << 4); }
+
+template <int BM, int BN, int WM, int WN, bool MANY_TAPS>
 __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp, int PLr) {
-  static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == kBN, "tile shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  unsigned char* sPh = dsm;                              // [PLr][kRowB] bf16 hi
-  unsigned char* sPl = sPh + PLr * kRowB;                // [PLr][kRowB] bf16 lo
-  float* sPre = reinterpret_cast<float*>(sPl + PLr * kRowB);   // [2][cchunks * 32] folded batch norm of this group
+  constexpr int TM = 2, TN = 2;
+  static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+  constexpr int kItems = kPMaxEntries * 2 / 256;         // (entry, octet) items per thread, at most
+  constexpr int WPARTS = 256 / BM;                       // threads per weight row
+  constexpr int WTAPS = (kTapGroup + WPARTS - 1) / WPARTS;   // taps per thread and group
+  __shared__ __attribute__((aligned(16))) unsigned char sP[2 * kPlane];
+  __shared__ __attribute__((aligned(16))) unsigned char sW[kTapGroup * BM * kPRow];
+  __shared__ __attribute__((aligned(16))) float sPre[2 * kMaxPre];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid - wm * WN;
   const int col = lane & 31, kh8 = lane >> 5;
@@ -286,9 +337,9 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
   const int HoWo = a.Ho * a.Wo, HW = a.H * a.W, HpWp = Hp * Wp;
   const int total = a.N * HoWo;
   const int taps = a.KH * a.KW;
-  const int cchunks = (a.cg + kKC - 1) / kKC;
-  const bool ragged = (a.cg % kKC) != 0;
-  const int npre = cchunks * kKC;
+  const int cchunks = (a.cg + kPC - 1) / kPC;
+  const bool ragged = (a.cg % kPC) != 0;
+  const float lim = a.alpha >= 0.f ? a.alpha : __builtin_inff();   // clamp_identity: no-op bounds
 
   // 32-bit index math throughout: the host takes this kernel only when N*Hp*Wp and N*C*H*W fit in 31 bits
   auto base_of = [&](int p) {
@@ -297,68 +348,47 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
     const int ho = r / a.Wo;
     return (n * Hp + ho) * Wp + (r - ho * a.Wo);
   };
-  const int p0 = blockIdx.x * kBN;
+  const int p0 = blockIdx.x * BN;
   const int bmin = base_of(p0);
-  int ep[TN];                                            // LDS byte offset of this lane's pixel row, per column tile
+  const float* xg = a.x + (long long)grp * a.cg * HW;
+
+  if (a.pre_scale) {
+    for (int c = tid; c < cchunks * kPC; c += 256) {
+      const int cs = grp * a.cg + min(c, a.cg - 1);
+      sPre[c] = a.pre_scale[cs];
+      sPre[kMaxPre + c] = a.pre_shift[cs];
+    }
+  }
+
+  // ---- per-lane fragment addresses (fixed for the whole kernel)
+  int e_pix[TN];                                         // patch entry of this lane's pixel, per column tile
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pix = p0 + (wn * TN + j) * 32 + col;
-    ep[j] = (pix < total ? (base_of(pix) - bmin) * kRowB : 0) + kh8 * 16;
+    e_pix[j] = pix < total ? base_of(pix) - bmin : 0;
   }
-  const float* xg = a.x + (long long)grp * a.cg * HW;
-
-  // Weights never touch LDS: an A fragment (out-channel row = lane & 31, 8 channels) is ONE byte of the
-  // packed plane.  Per chunk each lane loads the words of its TM rows for a group of taps (issued before
-  // the patch staging, so their latency hides behind it), keeps the two bytes it needs (k-steps 0 / 1)
-  // and expands them to +-1 bf16 on the VALU, which is otherwise idle next to the MFMAs.
-  constexpr int kTapGroup = 9;
-  const unsigned long long* wrow[TM];
-  bool wrow_ok[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int ol = (wm * TM + i) * 32 + col;
-    wrow_ok[i] = t * BM + ol < a.og_pad;
-    wrow[i] = a.wbits + o_pad0 + (wrow_ok[i] ? ol : 0);
-  }
-  unsigned wraw[kTapGroup][TM];                          // the 32 sign bits of (row, tap, chunk) as loaded
-  unsigned wpk[kTapGroup][TM];                           // byte 0: k-step 0, byte 1: k-step 1 of this lane's octet
-  auto issue_wloads = [&](unsigned (&dst)[kTapGroup][TM], int tg, int cc) {
-    const int c0 = cc * kKC;
+  int b_addr[kTapGroup][TN];                             // hi-plane byte address of the B fragment, first tap group
+  {
+    int kh = 0, kw = 0;
 #pragma unroll
     for (int tt = 0; tt < kTapGroup; ++tt) {
-      const int tap = min(tg + tt, taps - 1);
-      const int word = (tap * a.Gg + (c0 >> 6)) * a.opad_total;
+      const int toff = kh * a.dh * Wp + kw * a.dw;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        dst[tt][i] = reinterpret_cast<const unsigned*>(wrow[i] + word)[(c0 >> 5) & 1];
+      for (int j = 0; j < TN; ++j) b_addr[tt][j] = swz(e_pix[j] + (tt < taps ? toff : 0), kh8);
+      if (++kw == a.KW) { kw = 0; ++kh; }
     }
-  };
-  auto pack_w = [&](const unsigned (&src)[kTapGroup][TM]) {
+  }
+  int a_addr[TM];
 #pragma unroll
-    for (int tt = 0; tt < kTapGroup; ++tt)
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const unsigned v = wrow_ok[i] ? src[tt][i] >> (kh8 * 8) : 0u;
-        wpk[tt][i] = (v & 0xFFu) | ((v >> 8) & 0xFF00u);
-      }
-  };
-  // 8 sign bits -> 8 bf16 +-1 (bit set = +1): 0x3F80 with the sign bit taken from the inverted bit
-  auto expand = [&](unsigned byte, Frag& f) {
-    const unsigned nb = ~byte;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      f.u[q] = 0x3F803F80u | ((nb << (15 - 2 * q)) & 0x8000u) | ((nb << (30 - 2 * q)) & 0x80000000u);
-  };
+  for (int i = 0; i < TM; ++i) a_addr[i] = swz((wm * TM + i) * 32 + col, kh8);
 
-  // patch staging: item = (entry, channel octet), PLr / 64 <= kMaxItems items per thread; the octet is
-  // uniform per wave (PLr % 64 == 0).  The 8 loads of every item of chunk cc+1 are issued before the MFMA
-  // loop of chunk cc and consumed after it: one memory latency per chunk, hidden behind the matrix work.
-  const int n_items = PLr >> 6;
-  int it_off[kMaxItems], it_dst[kMaxItems], it_oct[kMaxItems];
+  // ---- patch staging roles: item = (entry, channel octet); the octet is uniform per wave (PLr % 128 == 0)
+  const int n_items = PLr >> 7;
+  int it_off[kItems], it_dst[kItems];
 #pragma unroll
-  for (int u = 0; u < kMaxItems; ++u) {
+  for (int u = 0; u < kItems; ++u) {
     const int i = tid + 256 * u;
-    const int oct = (i >= PLr) + (i >= 2 * PLr) + (i >= 3 * PLr);
+    const int oct = i >= PLr;
     const int e = i - oct * PLr;
     const int L = bmin + e;
     const int n = L / HpWp;
@@ -367,36 +397,37 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
     const int hi = hp - a.ph, wi = rem - hp * Wp - a.pw;
     const bool inside = u < n_items && n < a.N && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
     it_off[u] = inside ? n * a.C * HW + hi * a.W + wi : -1;
-    it_dst[u] = e * kRowB + oct * 16;
-    it_oct[u] = oct;
+    it_dst[u] = swz(e, oct) | (oct << 30);               // bit 30 carries the octet
   }
-  float raw[kMaxItems][8];
-  auto issue_loads = [&](int cc) {
-    // halo / padded channels read a valid dummy address and are zeroed at conversion
+  float raw[kItems][8];
+  auto issue_xloads = [&](int cc) {
+    // address = wave-uniform channel base (scalar registers) + the lane's 32-bit byte offset, which never
+    // changes: no vector address arithmetic.  Halo / padded channels read a valid dummy address and are
+    // zeroed at conversion.
 #pragma unroll
-    for (int u = 0; u < kMaxItems; ++u) {
+    for (int u = 0; u < kItems; ++u) {
       if (u < n_items) {
-        const int c0 = cc * kKC + it_oct[u] * 8;
-        const float* xp = xg + (it_off[u] < 0 ? 0 : it_off[u]);
+        const int c0 = __builtin_amdgcn_readfirstlane(cc * kPC + (it_dst[u] >> 30) * 8);
+        const unsigned boff = it_off[u] < 0 ? 0u : (unsigned)it_off[u] * 4u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int c = ragged ? min(c0 + j, a.cg - 1) : c0 + j;
-          raw[u][j] = xp[c * HW];
+          const char* cbase = reinterpret_cast<const char*>(xg + (long long)min(c0 + j, a.cg - 1) * HW);
+          raw[u][j] = *reinterpret_cast<const float*>(cbase + boff);
         }
       }
     }
   };
   auto convert_store = [&](int cc) {
 #pragma unroll
-    for (int u = 0; u < kMaxItems; ++u) {
+    for (int u = 0; u < kItems; ++u) {
       if (u < n_items) {
-        const int c0 = cc * kKC + it_oct[u] * 8;
+        const int c0 = cc * kPC + (it_dst[u] >> 30) * 8;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = raw[u][j];
         if (a.pre_scale) {                               // wave-uniform addresses: broadcast LDS reads
           const float4* ps = reinterpret_cast<const float4*>(sPre + c0);
-          const float4* pb = reinterpret_cast<const float4*>(sPre + npre + c0);
+          const float4* pb = reinterpret_cast<const float4*>(sPre + kMaxPre + c0);
           const float4 s0 = ps[0], s1 = ps[1], b0 = pb[0], b1 = pb[1];
           v[0] = fmaf(v[0], s0.x, b0.x); v[1] = fmaf(v[1], s0.y, b0.y);
           v[2] = fmaf(v[2], s0.z, b0.z); v[3] = fmaf(v[3], s0.w, b0.w);
@@ -405,12 +436,53 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          v[j] = (it_off[u] >= 0 && (!ragged || c0 + j < a.cg)) ? clamp_sym(v[j], a.alpha) : 0.f;
+          v[j] = (it_off[u] >= 0 && (!ragged || c0 + j < a.cg)) ? __builtin_amdgcn_fmed3f(v[j], -lim, lim) : 0.f;
         unsigned hi[4], lo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
-        *reinterpret_cast<uint4*>(sPh + it_dst[u]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        *reinterpret_cast<uint4*>(sPl + it_dst[u]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        const int dst = it_dst[u] & 0xFFFFF;
+        *reinterpret_cast<uint4*>(sP + dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(sP + kPlane + dst) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+    }
+  };
+
+  // ---- weight staging roles: thread -> out-channel row (tid % BM), taps part + WPARTS * k of the group
+  const int so = tid % BM, part = tid / BM;
+  const bool so_valid = t * BM + so < a.og_pad;
+  const unsigned* wcol = reinterpret_cast<const unsigned*>(a.wbits + o_pad0 + (so_valid ? so : 0));
+  unsigned one_bf16x2;                                   // 0x3F803F80 held in a vector register (one scalar operand per VALU op)
+  asm volatile("v_mov_b32 %0, 0x3f803f80" : "=v"(one_bf16x2));
+  unsigned wraw[WTAPS];
+  auto issue_wloads = [&](unsigned (&dst)[WTAPS], int tg, int cc) {
+    const int c0 = cc * kPC;
+#pragma unroll
+    for (int k = 0; k < WTAPS; ++k) {
+      const int tap = min(tg + part + WPARTS * k, taps - 1);
+      dst[k] = wcol[2 * ((tap * a.Gg + (c0 >> 6)) * a.opad_total) + ((c0 >> 5) & 1)];
+    }
+  };
+  auto expand_store = [&](const unsigned (&src)[WTAPS], int tg, int cc) {
+    const int sh = (cc * kPC) & 16;
+#pragma unroll
+    for (int k = 0; k < WTAPS; ++k) {
+      const int ts = part + WPARTS * k;
+      if (ts < kTapGroup && tg + ts < taps) {
+        // 16 sign bits (set = +1) -> 16 bf16.  The inverted bits replicated into both 16-bit halves, one
+        // packed 16-bit shift moves bit 2q / 2q+1 to the sign position of the low / high half, one
+        // and-or merges it into 0x3F80 (= 1.0): two VALU ops per pair of weights.
+        const unsigned m = so_valid ? ~(src[k] >> sh) & 0xFFFFu : 0xFFFFu;     // rows past the group: -1 * 0 anyway
+        const u16x2 rep = __builtin_bit_cast(u16x2, m | (m << 16));
+        unsigned d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const u16x2 shq = {(unsigned short)(15 - 2 * q), (unsigned short)(14 - 2 * q)};
+          const unsigned xq = __builtin_bit_cast(unsigned, rep << shq);
+          asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d[q]) : "v"(xq), "s"(0x80008000u), "v"(one_bf16x2));
+        }
+        unsigned char* row = sW + ts * (BM * kPRow);
+        *reinterpret_cast<uint4*>(row + swz(so, 0)) = make_uint4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4*>(row + swz(so, 1)) = make_uint4(d[4], d[5], d[6], d[7]);
       }
     }
   };
@@ -423,63 +495,99 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  issue_loads(0);
-  issue_wloads(wraw, 0, 0);
-  if (a.pre_scale) {
-    for (int c = tid; c < npre; c += 256) {
-      const int cs = grp * a.cg + min(c, a.cg - 1);
-      sPre[c] = a.pre_scale[cs];
-      sPre[npre + c] = a.pre_shift[cs];
+  auto mfma_tap = [&](int tt, const int (&baddr)[TN]) {
+    Frag af[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(sW + tt * (BM * kPRow) + a_addr[i]);
+      af[i].u[0] = v.x; af[i].u[1] = v.y; af[i].u[2] = v.z; af[i].u[3] = v.w;
     }
-    __syncthreads();
-  }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const uint4 vh = *reinterpret_cast<const uint4*>(sP + baddr[j]);
+      const uint4 vl = *reinterpret_cast<const uint4*>(sP + kPlane + baddr[j]);
+      bh[j].u[0] = vh.x; bh[j].u[1] = vh.y; bh[j].u[2] = vh.z; bh[j].u[3] = vh.w;
+      bl[j].u[0] = vl.x; bl[j].u[1] = vl.y; bl[j].u[2] = vl.z; bl[j].u[3] = vl.w;
+    }
+    // hi products of all four tiles first, then lo: dependent MFMAs on one accumulator are 4 apart
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bl[j].v, acc[i][j], 0, 0, 0);
+  };
+
+  issue_xloads(0);
+  issue_wloads(wraw, 0, 0);
+  __syncthreads();                                       // sPre visible
   for (int cc = 0; cc < cchunks; ++cc) {
     convert_store(cc);
-    pack_w(wraw);
-    __syncthreads();                                     // patch of this chunk visible
-    if (cc + 1 < cchunks) {                              // next chunk's loads fly during the MFMAs below
-      issue_loads(cc + 1);
-      issue_wloads(wraw, 0, cc + 1);
-    }
-    int kh = 0, kw = 0;
-    for (int tg = 0; tg < taps; tg += kTapGroup) {
-      if (tg) {                                          // more than 9 taps: later groups are loaded in place
-        unsigned wtmp[kTapGroup][TM];                    // (wraw already holds the next chunk's first group)
-        issue_wloads(wtmp, tg, cc);
-        pack_w(wtmp);
+    expand_store(wraw, 0, cc);
+    __syncthreads();                                     // patch and first tap group of this chunk visible
+    if constexpr (!MANY_TAPS) {
+      if (cc + 1 < cchunks) {                            // next chunk's loads fly during the MFMAs below
+        issue_xloads(cc + 1);
+        issue_wloads(wraw, 0, cc + 1);
       }
 #pragma unroll
-      for (int tt = 0; tt < kTapGroup; ++tt) {
-        if (tg + tt < taps) {
-          const int toff = (kh * a.dh * Wp + kw * a.dw) * kRowB;
+      for (int tt = 0; tt < kTapGroup; ++tt)
+        if (tt < taps) mfma_tap(tt, b_addr[tt]);
+    } else {
+      // more than 9 taps (5x5 ...): later groups are staged in place, B addresses recomputed per tap
+      int kh = 0, kw = 0;
+      for (int tg = 0; tg < taps; tg += kTapGroup) {
+        if (tg) {
+          unsigned wtmp[WTAPS];
+          issue_wloads(wtmp, tg, cc);
+          __syncthreads();                               // previous group's fragment reads finished
+          expand_store(wtmp, tg, cc);
+          __syncthreads();
+        }
+        for (int tt = 0; tt < kTapGroup && tg + tt < taps; ++tt) {
+          const int toff = kh * a.dh * Wp + kw * a.dw;
+          int baddr[TN];
 #pragma unroll
-          for (int ks = 0; ks < kKC / 16; ++ks) {
-            Frag af[TM], bh[TN], bl[TN];
+          for (int j = 0; j < TN; ++j) baddr[j] = swz(e_pix[j] + toff, kh8);
+          // (tt is not a compile-time constant here: the A offset becomes an address add)
+          Frag af[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const int row = ep[j] + toff + ks * 32;
-              const uint4 vh = *reinterpret_cast<const uint4*>(sPh + row);
-              const uint4 vl = *reinterpret_cast<const uint4*>(sPl + row);
-              bh[j].u[0] = vh.x; bh[j].u[1] = vh.y; bh[j].u[2] = vh.z; bh[j].u[3] = vh.w;
-              bl[j].u[0] = vl.x; bl[j].u[1] = vl.y; bl[j].u[2] = vl.z; bl[j].u[3] = vl.w;
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) expand(wpk[tt][i] >> (8 * ks), af[i]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bh[j].v, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bl[j].v, acc[i][j], 0, 0, 0);
-              }
+          for (int i = 0; i < TM; ++i) {
+            const uint4 v = *reinterpret_cast<const uint4*>(sW + tt * (BM * kPRow) + a_addr[i]);
+            af[i].u[0] = v.x; af[i].u[1] = v.y; af[i].u[2] = v.z; af[i].u[3] = v.w;
           }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const uint4 vh = *reinterpret_cast<const uint4*>(sP + baddr[j]);
+            const uint4 vl = *reinterpret_cast<const uint4*>(sP + kPlane + baddr[j]);
+            bh[j].u[0] = vh.x; bh[j].u[1] = vh.y; bh[j].u[2] = vh.z; bh[j].u[3] = vh.w;
+            bl[j].u[0] = vl.x; bl[j].u[1] = vl.y; bl[j].u[2] = vl.z; bl[j].u[3] = vl.w;
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bh[j].v, acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bl[j].v, acc[i][j], 0, 0, 0);
           if (++kw == a.KW) { kw = 0; ++kh; }
         }
       }
+      if (cc + 1 < cchunks) {
+        issue_xloads(cc + 1);
+        issue_wloads(wraw, 0, cc + 1);
+      }
     }
-    __syncthreads();                                     // every wave is done reading before the patch is rewritten
+    __syncthreads();                                     // every wave is done reading before LDS is rewritten
   }
-  store_tiles<BM, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
+  store_tiles<unsigned, BM, BN, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
 }
 
 }  // namespace
@@ -516,40 +624,38 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
   const bool wide = a.og > 64;
   const int bm = wide ? 128 : 64;
   a.tiles_per_group = (a.og + bm - 1) / bm;
-  // stride-1 layers whose 128-pixel input patch fits LDS twice per CU take the patch kernel
+  // stride-1 layers whose input patch fits the LDS planes take the patch kernel: 128 out-channels x 128
+  // pixels per workgroup, or 64 x 256 for narrow layers (the patch conversion is shared by more pixels)
   const int Hp = g->H + 2 * g->pad_h, Wp = g->W + 2 * g->pad_w;
-  const long long patch = 128 + (127 / Wo + 1) * (long long)(Wp - Wo) + (127 / (Ho * Wo) + 1) * (long long)(Hp - Ho) * Wp +
-                          (long long)(g->KH - 1) * g->dil_h * Wp + (long long)(g->KW - 1) * g->dil_w;
-  const int PLr = (int)((patch + 63) / 64 * 64);
-  const int cg_pad = (a.cg + kKC - 1) / kKC * kKC;
-  const size_t patch_lds = (size_t)2 * PLr * kRowB + (pre_scale ? (size_t)2 * cg_pad * 4 : 0);
-  bool use_patch = g->stride_h == 1 && g->stride_w == 1 && PLr <= 64 * kMaxItems && patch_lds <= 80 * 1024 &&
-                   (long long)g->N * g->C * g->H * g->W < (1ll << 31) && (long long)g->N * Hp * Wp + PLr < (1ll << 31);
+  const int pbn = wide ? 128 : 256;
+  const long long patch = pbn + ((pbn - 1) / Wo + 1) * (long long)(Wp - Wo) +
+                          ((pbn - 1) / (Ho * Wo) + 1) * (long long)(Hp - Ho) * Wp +
+                          (long long)(g->KH - 1) * g->dil_h * Wp + (long long)(g->KW - 1) * g->dil_w + 1;
+  const int PLr = (int)((patch + 127) / 128 * 128);
+  bool use_patch = g->stride_h == 1 && g->stride_w == 1 && PLr <= kPMaxEntries &&
+                   (!pre_scale || (a.cg + kPC - 1) / kPC * kPC <= kMaxPre) &&
+                   (long long)g->N * g->C * g->H * g->W < (1ll << 30) && (long long)g->N * Hp * Wp + PLr < (1ll << 31) &&
+                   (long long)g->N * g->O * Ho * Wo < (1ll << 30);
 #ifdef LSQ_TUNE
   if (getenv("LSQ_SIGNW_NOPATCH")) use_patch = false;
 #endif
-  if (use_patch) {
-    static bool attr_done = false;       // benign race: the attribute is idempotent
-    if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)signw_conv_patch<128, 2, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-          hipFuncSetAttribute((const void*)signw_conv_patch<64, 1, 4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-        return (int)hipGetLastError();
-      attr_done = true;
-    }
-  }
   for (int q = 0; q < kw_planes; ++q) {
     a.wbits = (const unsigned long long*)wbits + (long long)q * wplane_words;
     a.wscale = wscales + (long long)q * g->O;
     a.accumulate = q ? 1 : 0;
     a.final_pass = q == kw_planes - 1 ? 1 : 0;
-    dim3 grid((unsigned)((total + kBN - 1) / kBN), (unsigned)(g->groups * a.tiles_per_group));
+    const unsigned otiles = (unsigned)(g->groups * a.tiles_per_group);
     if (use_patch) {
-      if (wide) hipLaunchKernelGGL((signw_conv_patch<128, 2, 2, 2, 2>), grid, dim3(256), patch_lds, st, a, Hp, Wp, PLr);
-      else hipLaunchKernelGGL((signw_conv_patch<64, 1, 4, 2, 1>), grid, dim3(256), patch_lds, st, a, Hp, Wp, PLr);
-    } else if (wide) {
-      hipLaunchKernelGGL((signw_conv_tiled<128, 2, 2, 2, 2>), grid, dim3(256), 0, st, a);
+      dim3 grid((unsigned)((total + pbn - 1) / pbn), otiles);
+      const bool many = g->KH * g->KW > kTapGroup;
+      if (wide && !many) hipLaunchKernelGGL((signw_conv_patch<128, 128, 2, 2, false>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
+      else if (wide) hipLaunchKernelGGL((signw_conv_patch<128, 128, 2, 2, true>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
+      else if (!many) hipLaunchKernelGGL((signw_conv_patch<64, 256, 1, 4, false>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
+      else hipLaunchKernelGGL((signw_conv_patch<64, 256, 1, 4, true>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
     } else {
-      hipLaunchKernelGGL((signw_conv_tiled<64, 1, 4, 2, 1>), grid, dim3(256), 0, st, a);
+      dim3 grid((unsigned)((total + kBN - 1) / kBN), otiles);
+      if (wide) hipLaunchKernelGGL((signw_conv_tiled<128, 2, 2, 2, 2>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((signw_conv_tiled<64, 1, 4, 2, 1>), grid, dim3(256), 0, st, a);
     }
     if (int e = (int)hipGetLastError()) return e;
   }

@@ -191,7 +191,17 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
 #pragma unroll
   for (int p = 0; p < KX; ++p) xs[p] = a.xscales[(long long)p * a.N + n];
   const int full = a.cg * taps;
-  float* yp = a.y + ((long long)n * a.O + o0) * HoWo + r;
+  const long long ybase = ((long long)n * a.O + o0) * HoWo + r;
+  float* yp = a.y + ybase;
+  // the residual loads are issued together, before the first store: a load consumed right after it is
+  // issued costs one memory latency per out-channel.  One residual array in registers (the block adds its
+  // shortcut either before or after the ReLU); with both present the second is read in place.
+  const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
+  const float* rsrc = want_pre ? a.res_pre : a.res_post;
+  float rv[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o)
+    rv[o] = (want_pre || want_post) ? rsrc[ybase + (o < o_valid ? (long long)o * HoWo : 0)] : 0.f;
 #pragma unroll
   for (int o = 0; o < OT; ++o) {
     if (o < o_valid) {
@@ -199,13 +209,11 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
 #pragma unroll
       for (int p = 0; p < KX; ++p) v += xs[p] * (float)(full - 2 * acc[p][o] + corr[o]);
       v *= a.wscale[o0 + o];
-      const float base = a.accumulate ? yp[(long long)o * HoWo] : (a.bias ? a.bias[o0 + o] : 0.f);
-      float out = base + v;
+      float out = (a.accumulate ? yp[(long long)o * HoWo] : (a.bias ? a.bias[o0 + o] : 0.f)) + v;
       if (a.final_pass) {        // fused block epilogue (non-linearity and shortcut adds of resnet.py:182-190)
-        const long long yi = ((long long)n * a.O + o0 + o) * HoWo + r;
-        if (a.res_pre) out += a.res_pre[yi];
+        if (want_pre) out += rv[o];
         if (a.relu) out = fmaxf(out, 0.f);
-        if (a.res_post) out += a.res_post[yi];
+        if (want_post) out += want_pre ? a.res_post[ybase + (long long)o * HoWo] : rv[o];
       }
       yp[(long long)o * HoWo] = out;
     }
