@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 2
+#define LSQ_ABI_VERSION 3
 
 /* quantization schemes (quant/binary/binary_conv.py:99-101) */
 enum {
@@ -154,6 +154,18 @@ int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, 
                      const float* wscales, const float* bias, const lsq_conv_geom* g,
                      int relu, const float* res_pre, const float* res_post,
                      float* y, void* stream);
+
+/*
+ * Stem tail in front of the first quantized convolution:
+ *   y[n][c][ho][wo] = act( max_{kh,kw} x[n][ho*stride-pad+kh][wo*stride-pad+kw][c] + bias[c] ),  act = ReLU or identity
+ * x is channels-last (NHWC, the layout MIOpen's convolution is fastest in), y is NCHW (what lsq_act_quant
+ * reads).  Replaces nn.ReLU + nn.MaxPool2d of the reference's first block in eval mode
+ * (quant/models/resnet.py: Sequential(conv1, bn1, relu, maxpool), forward :393-397) once the batch norm is
+ * folded into the convolution: bias and ReLU commute with the max.  Padding behaves like
+ * nn.MaxPool2d (-inf), 2*pad <= kernel, floor mode, no dilation.  bias may be NULL.
+ */
+int lsq_pool_bias_relu_nhwc(const float* x_nhwc, int N, int C, int H, int W, int kernel, int stride, int pad,
+                            const float* bias, int relu, float* y_nchw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 
@@ -62,6 +62,8 @@ def _declare(lib):
     lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_signw_conv2d.restype = i32
     lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
+    lib.lsq_pool_bias_relu_nhwc.restype = i32
+    lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
 
 
 def lib():
@@ -235,3 +237,19 @@ def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: to
                                      None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wscales.shape[0],
                                      wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu), ptr(res_pre),
                                      ptr(res_post), y.data_ptr(), stream_ptr()), 'lsq_signw_conv2d')
+
+
+def pool_bias_relu_nhwc(x: torch.Tensor, kernel: int, stride: int, pad: int, bias: Optional[torch.Tensor],
+                        relu: bool) -> torch.Tensor:
+    """``relu(max_pool2d(x) + bias)`` of a channels-last fp32 tensor ``x`` (logical shape [N, C, H, W]) as
+    one kernel that writes a contiguous NCHW tensor."""
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise LsqHipError('pool_bias_relu_nhwc needs a channels-last fp32 4-d tensor')
+    n, c, h, w = x.shape
+    ho, wo = (h + 2 * pad - kernel) // stride + 1, (w + 2 * pad - kernel) // stride + 1
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    with _Timed('lsq_pool_bias_relu_nhwc', 4 * x.numel() + 4 * y.numel(), 0):
+        check(lib().lsq_pool_bias_relu_nhwc(x.data_ptr(), n, c, h, w, kernel, stride, pad,
+                                            ptr(None if bias is None else _f32c(bias)), int(relu), y.data_ptr(),
+                                            stream_ptr()), 'lsq_pool_bias_relu_nhwc')
+    return y

@@ -13,6 +13,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 import torch.nn as nn
 
+from quant import _hip
 from quant.binary.binary_conv import QuantConv2d
 
 non_linearity_map = {'relu': nn.ReLU, 'prelu': nn.PReLU, 'identity': nn.Identity}
@@ -47,10 +48,22 @@ def _folded_conv_bn(owner: nn.Module, conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return hit[1], hit[2]
 
 
+def _square_pool(pool: nn.Module):
+    """(kernel, stride, pad) when ``pool`` is a plain square floor-mode ``nn.MaxPool2d``, else None."""
+    if not isinstance(pool, nn.MaxPool2d) or pool.ceil_mode or pool.return_indices:
+        return None
+    pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)     # noqa: E731
+    k, s, p, d = pair(pool.kernel_size), pair(pool.stride), pair(pool.padding), pair(pool.dilation)
+    if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or d != (1, 1) or 2 * p[0] > k[0]:
+        return None
+    return k[0], s[0], p[0]
+
+
 class _Stem(nn.Sequential):
     """``Sequential(conv1, bn1, relu, maxpool)`` of the reference (same keys).  Eval mode on the GPU: batch
-    norm folded into the convolution's weights and the max-pool taken before the ReLU (they commute), so
-    the ReLU runs on the pooled tensor -- an inference-only rewrite of stock PyTorch ops, no custom kernel."""
+    norm folded into the convolution's weights, MIOpen's convolution in channels-last, and the tail
+    (max-pool, bias, ReLU -- bias and ReLU commute with the max -- and the layout change to the NCHW tensor
+    the quantizer reads) as one kernel, ``lsq_pool_bias_relu_nhwc``."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         conv, bn, relu, pool = self[0], self[1], self[2], self[3]
@@ -62,11 +75,16 @@ class _Stem(nn.Sequential):
             hit = self.__dict__.get('_folded_cl')
             if hit is None or hit[0] is not w:
                 hit = self.__dict__['_folded_cl'] = (w, w.contiguous(memory_format=torch.channels_last))
-            y = pool(nn.functional.conv2d(x.contiguous(memory_format=torch.channels_last), hit[1], None,
-                                          conv.stride, conv.padding, conv.dilation, conv.groups))
+            y = nn.functional.conv2d(x.contiguous(memory_format=torch.channels_last), hit[1], None,
+                                     conv.stride, conv.padding, conv.dilation, conv.groups)
+            geom = _square_pool(pool)
+            if geom is not None and isinstance(relu, nn.ReLU) and y.is_contiguous(memory_format=torch.channels_last):
+                # pool + bias + ReLU + NHWC -> NCHW in one HBM pass (csrc/lsq_pool.hip)
+                return _hip.pool_bias_relu_nhwc(y, *geom, b, True)
+            y = pool(y)
             out = torch.empty(y.shape, dtype=y.dtype, device=y.device)
             torch.add(y, b.view(1, -1, 1, 1), out=out)
-            return out.relu_()
+            return relu(out)
         return pool(relu(bn(conv(x))))
 
 

@@ -668,3 +668,27 @@ def test_full_size_properties():
         wq = conv.w_approximate.v1.view(-1, 1, 1, 1) / 2 * P.pm1(conv.weight)
         ref = torch.nn.functional.conv2d(xq.double(), wq.double(), conv.bias.double(), 1, 1).float()
     assert rel_err(y1, ref) <= TOL
+
+
+@pytest.mark.parametrize('shape, k, stride, pad', [
+    ((3, 64, 112, 112), 3, 2, 1),      # the ResNet stem
+    ((2, 70, 37, 141), 3, 2, 1),       # ragged channel tile, more than 64 output columns, odd sizes
+    ((2, 5, 9, 9), 2, 2, 0),
+    ((1, 130, 8, 8), 3, 1, 1),
+    ((2, 16, 12, 10), 5, 3, 2),
+])
+def test_stem_tail_pool_bias_relu_kernel(shape, k, stride, pad):
+    """lsq_pool_bias_relu_nhwc == relu(max_pool2d(x) + b), bit-exact (max, one add, max), for channels-last
+    input and NCHW output; without bias / ReLU as well; C-ABI argument errors."""
+    import torch.nn.functional as F
+    hip = _hip()
+    x = detgen.normal(f'gpu.pool.x{shape}', shape).to(DEV).contiguous(memory_format=torch.channels_last)
+    b = detgen.normal(f'gpu.pool.b{shape}', (shape[1],)).to(DEV)
+    ref = F.max_pool2d(x, k, stride, pad)
+    y = hip.pool_bias_relu_nhwc(x, k, stride, pad, b, True)
+    assert y.is_contiguous() and torch.equal(y, (ref + b.view(1, -1, 1, 1)).relu())
+    assert torch.equal(hip.pool_bias_relu_nhwc(x, k, stride, pad, None, False), ref.contiguous())
+    with pytest.raises(hip.LsqHipError):
+        hip.pool_bias_relu_nhwc(x.contiguous(), k, stride, pad, b, True)          # NCHW input
+    assert hip.lib().lsq_pool_bias_relu_nhwc(None, 1, 1, 4, 4, 2, 2, 0, None, 0, y.data_ptr(), None) == -1       # LSQ_E_NULL
+    assert hip.lib().lsq_pool_bias_relu_nhwc(x.data_ptr(), 1, 1, 4, 4, 2, 2, 2, None, 0, y.data_ptr(), None) != 0   # 2*pad > k
