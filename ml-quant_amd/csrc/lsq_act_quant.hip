@@ -28,8 +28,10 @@ namespace lsq {
 #ifdef LSQ_PHASE_CLOCKS
 __device__ long long g_phase_clocks[32];
 #define LSQ_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)clock64(); } while (0)
+#define LSQ_NOTE(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)(v); } while (0)
 #else
 #define LSQ_MARK(i) do {} while (0)
+#define LSQ_NOTE(i, v) do {} while (0)
 #endif
 namespace {
 
@@ -190,6 +192,21 @@ __device__ __forceinline__ MPair m_pair(double lo_cnt, double lo_sum, double n, 
   return r;
 }
 
+// a / b for the conservative bin tests only: hardware reciprocal + one Newton step (relative error ~1e-15,
+// far inside kSlack) instead of the ~45-instruction IEEE division; b >= 1 here.
+__device__ __forceinline__ double quick_div(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return a * r;
+}
+__device__ __forceinline__ MPair m_pair_quick(double lo_cnt, double lo_sum, double n, double total) {
+  const double hi_mean = quick_div(total - lo_sum, n - lo_cnt);
+  MPair r;
+  r.m2 = 0.5 * hi_mean;
+  r.m1 = 0.5 * (quick_div(lo_sum, lo_cnt) + hi_mean);
+  return r;
+}
+
 // Can a position inside [r0, r0+cnt) be a candidate (optimal.py:78-80)?  Conservative.
 __device__ bool may_hold_candidate(unsigned r0, unsigned cnt, double p0, double s, double vlo, double vhi,
                                    double next_hi, unsigned n, double total, bool ternary) {
@@ -199,14 +216,14 @@ __device__ bool may_hold_candidate(unsigned r0, unsigned cnt, double p0, double 
   if (ilo > ihi) return false;
   double m2_lo, m1_lo, m2_hi, m1_hi, succ_hi;
   if (r0 >= 1u) {
-    const MPair m = m_pair((double)r0, p0, (double)n, total);
+    const MPair m = m_pair_quick((double)r0, p0, (double)n, total);
     m2_lo = m.m2;
     m1_lo = m.m1;
   } else {
-    m2_lo = m1_lo = 0.5 * (total - vhi) / ((double)n - 1.0);
+    m2_lo = m1_lo = 0.5 * quick_div(total - vhi, (double)n - 1.0);
   }
   if (r1 <= (long long)n - 1) {
-    const MPair m = m_pair((double)r1, p0 + s, (double)n, total);
+    const MPair m = m_pair_quick((double)r1, p0 + s, (double)n, total);
     m2_hi = m.m2;
     m1_hi = m.m1;
     succ_hi = next_hi;
@@ -854,6 +871,8 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
   const unsigned seg_n = s1.cnt;
   unsigned long long* const h = lds->u.whist[wid];
   unsigned* const wk = lds->wkeys[wid];
+  LSQ_MARK(20);
+  LSQ_NOTE(25, seg_n);
 #pragma unroll
   for (int u = 0; u < 4; ++u) h[lane * 4 + u] = 0ull;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -862,6 +881,7 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
     atomicAdd(&h[(key >> kWaveShift) & (kWaveSub - 1)], kOne | (unsigned long long)(key & ((1u << kWaveShift) - 1u)));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  LSQ_MARK(21);
   unsigned c[4], lane_cnt = 0, first_sub = kNoKey;
   double sm[4], lane_sum = 0.0;
 #pragma unroll
@@ -923,6 +943,8 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
     }
   }
   bool ok = true;
+  LSQ_MARK(22);
+  LSQ_NOTE(26, __popcll(__ballot(fl[0])) + __popcll(__ballot(fl[1])) + __popcll(__ballot(fl[2])) + __popcll(__ballot(fl[3])));
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     unsigned long long todo = __ballot(fl[u]);
@@ -1013,6 +1035,7 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
+  LSQ_MARK(23);
   WaveOut wo;
   wo.best = best;
   wo.ok = ok ? 1 : 0;
@@ -1068,10 +1091,12 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
       if (key < *sp) atomicMin(sp, key);
     }
   };
-  // The gather needs no bit packing, so it does not use the lane = pixel sweep: a flat, fully coalesced
-  // float4 walk keeps all 1024 lanes busy whatever the layer's H*W is.  flat = 4*i, so flat % 3 = i % 3
-  // and for skip = 3 exactly one of the first three elements is sub-sampled (plus the fourth when
-  // i % 3 == 0).  Two phases per batch of U loads keep the returning LDS atomics in flight together.
+  // The gather needs no bit packing, so it does not use the lane = pixel sweep: a flat walk keeps all 1024
+  // lanes busy whatever the layer's H*W is.  For skip = 3 a lane takes THREE consecutive float4s (12
+  // elements starting at a multiple of 12): the sub-sampled elements are then always x of the first, w of
+  // the first, z of the second and y of the third -- four keys per three loads, no per-lane phase
+  // bookkeeping, every loaded line fully consumed by the three loads of the wave.  Two phases per batch
+  // keep the returning LDS atomics in flight together.
   const long long M = a.row_elems;
   const bool vec_ok = a.skip == 3 && (M % 4) == 0 && (((uintptr_t)xrow) % 16) == 0 && n_rg != 0u &&
                       (a.pre_scale == nullptr || ((a.H * a.W) % 4) == 0);
@@ -1081,46 +1106,49 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
   }
   const float4* __restrict__ row4 = reinterpret_cast<const float4*>(xrow);
   const unsigned nvec = (unsigned)(M / 4);
+  const unsigned ntrip = (nvec + 2u) / 3u;
   const bool affine = a.pre_scale != nullptr;
-  const unsigned qv = (unsigned)(a.H * a.W) / 4u;      // float4s per channel (H*W % 4 == 0 checked below)
+  const unsigned qv = (unsigned)(a.H * a.W) / 4u;      // float4s per channel
   const float qinv = 1.0f / (float)(qv ? qv : 1u);
-  constexpr int U = 8;
-  unsigned rem0 = threadIdx.x % 3u;                  // (i % 3) for i = tid; advances by 1024 % 3 = 1 per step
-  for (unsigned i0 = threadIdx.x; i0 < nvec; i0 += kThreads * U) {
-    float4 v[U];
-    float scs[U], shs[U];
+  constexpr int U = 3;
+  for (unsigned j0 = threadIdx.x; j0 < ntrip; j0 += kThreads * U) {
+    float4 v[U][3];
+    float scs[U][3], shs[U][3];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const unsigned i = min(i0 + (unsigned)u * kThreads, nvec - 1u);
-      v[u] = row4[i];
-      scs[u] = 1.f;
-      shs[u] = 0.f;
-      if (affine) {                 // channel of this float4: i / qv via a reciprocal, corrected
-        unsigned c = (unsigned)((float)i * qinv);
-        if ((c + 1u) * qv <= i) ++c;
-        if (c * qv > i) --c;
-        scs[u] = a.pre_scale[c];
-        shs[u] = a.pre_shift[c];
+      const unsigned j = j0 + (unsigned)u * kThreads;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned i = min(3u * j + (unsigned)t, nvec - 1u);
+        v[u][t] = row4[i];
+        scs[u][t] = 1.f;
+        shs[u][t] = 0.f;
+        if (affine) {                 // channel of this float4: i / qv via a reciprocal, corrected
+          unsigned c = (unsigned)((float)i * qinv);
+          if ((c + 1u) * qv <= i) ++c;
+          if (c * qv > i) --c;
+          scs[u][t] = a.pre_scale[c];
+          shs[u][t] = a.pre_shift[c];
+        }
       }
     }
-    unsigned keys[U][2], pos[U][2];
-    bool tk[U][2];
-    unsigned rem = rem0;
+    unsigned keys[U][4], pos[U][4];
+    bool tk[U][4];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool live = i0 + (unsigned)u * kThreads < nvec;
-      float xs[2];
-      bool has[2];
-      xs[0] = rem == 0u ? v[u].x : (rem == 1u ? v[u].z : v[u].y);
-      has[0] = live;
-      xs[1] = v[u].w;
-      has[1] = live && rem == 0u;
-      if (affine) {
-        xs[0] = fmaf(xs[0], scs[u], shs[u]);
-        xs[1] = fmaf(xs[1], scs[u], shs[u]);
+      const unsigned j = j0 + (unsigned)u * kThreads;
+      const unsigned e0 = 12u * j;                     // flat index of the triple's first element
+      float xs[4];
+      xs[0] = fmaf(v[u][0].x, scs[u][0], shs[u][0]);   // (scale 1, shift 0 without a folded batch norm)
+      xs[1] = fmaf(v[u][0].w, scs[u][0], shs[u][0]);
+      xs[2] = fmaf(v[u][1].z, scs[u][1], shs[u][1]);
+      xs[3] = fmaf(v[u][2].y, scs[u][2], shs[u][2]);
+      if (!affine) {
+        xs[0] = v[u][0].x; xs[1] = v[u][0].w; xs[2] = v[u][1].z; xs[3] = v[u][2].y;
       }
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
+      for (int e = 0; e < 4; ++e) {
+        const bool has = j < ntrip && (long long)e0 + 3 * e < M;
         const unsigned key = abs_key(clamp_sym(xs[e], a.alpha));
         const unsigned bin = key >> L1_SHIFT;
         unsigned gs = kNoKey;
@@ -1130,10 +1158,10 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
           if (d < len[r]) gs = first[r] + d;
         }
         keys[u][e] = key;
-        tk[u][e] = has[e] && gs != kNoKey;
+        tk[u][e] = has && gs != kNoKey;
         pos[u][e] = 0u;
         if (tk[u][e]) pos[u][e] = atomicAdd(&lds->fill[gs], 1u);
-        if (has[e]) {
+        if (has) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (bin == succbin[r]) {
@@ -1143,14 +1171,12 @@ __device__ __forceinline__ void gather_keys(SolverLds* lds, const float* __restr
           }
         }
       }
-      rem = rem == 2u ? 0u : rem + 1u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < 4; ++e)
         if (tk[u][e]) list[pos[u][e]] = keys[u][e];
-    rem0 = (rem0 + (unsigned)(U % 3)) % 3u;
   }
 }
 
@@ -1183,61 +1209,106 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       for (unsigned si = 0; si < nslot; ++si) best = resolve_slot_block(lds, xrow, n, si, true, best);
     }
   } else if (tflag) {
-    if (tid == 0) {                                 // greedy split by gathered-key capacity
-      unsigned ns = 0, begin = 0, acc = 0;
-      for (unsigned q = 0; q < tflag; ++q) {
-        const unsigned cq = lds->slot[q].cnt;
-        if (q > begin && (acc + cq > (unsigned)kListExt || q - begin >= (unsigned)kSubSlots)) {
-          lds->sub_begin[ns++] = (unsigned short)begin;
-          begin = q;
-          acc = 0;
-        }
-        lds->slot[q].base = acc;
-        acc += cq;
+    // split the flagged bins into sub-rounds by gathered-key capacity.  Usual case: everything fits one
+    // round -- wave 0 turns the counts into list offsets with a scan; otherwise one lane splits greedily.
+    if (wid == 0) {
+      unsigned cq[4], lane_tot = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned q = (unsigned)lane * 4u + (unsigned)u;
+        cq[u] = q < tflag ? lds->slot[q].cnt : 0u;
+        lane_tot += cq[u];
       }
-      lds->sub_begin[ns++] = (unsigned short)begin;
-      lds->sub_begin[ns] = (unsigned short)tflag;
-      lds->n_sub = ns;
+      const unsigned incl = wave_incl_scan(lane_tot);
+      const unsigned all = (unsigned)__shfl((int)incl, 63);
+      if (all <= (unsigned)kListExt && tflag <= (unsigned)kSubSlots) {
+        unsigned acc = incl - lane_tot;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned q = (unsigned)lane * 4u + (unsigned)u;
+          if (q < tflag) lds->slot[q].base = acc;
+          acc += cq[u];
+        }
+        if (lane == 0) {
+          lds->sub_begin[0] = 0;
+          lds->sub_begin[1] = (unsigned short)tflag;
+          lds->n_sub = 1;
+        }
+      } else if (lane == 0) {
+        unsigned ns = 0, begin = 0, acc = 0;
+        for (unsigned q = 0; q < tflag; ++q) {
+          const unsigned c1 = lds->slot[q].cnt;
+          if (q > begin && (acc + c1 > (unsigned)kListExt || q - begin >= (unsigned)kSubSlots)) {
+            lds->sub_begin[ns++] = (unsigned short)begin;
+            begin = q;
+            acc = 0;
+          }
+          lds->slot[q].base = acc;
+          acc += c1;
+        }
+        lds->sub_begin[ns++] = (unsigned short)begin;
+        lds->sub_begin[ns] = (unsigned short)tflag;
+        lds->n_sub = ns;
+      }
     }
     __syncthreads();
     const unsigned n_sub = lds->n_sub;
     for (unsigned sr = 0; sr < n_sub; ++sr) {
       const unsigned sb = lds->sub_begin[sr], se = lds->sub_begin[sr + 1];
-      __syncthreads();
+      if (sr) __syncthreads();                         // the previous sub-round's list and slots are done with
       if (se - sb == 1u && lds->slot[sb].cnt > (unsigned)kListExt) {
         if (tid == 0) lds->dbg_rowpass += 1;
         best = resolve_slot_block(lds, xrow, n, sb, true, best);              // one huge bin: histogram straight from the row
         continue;
       }
-      if (tid == 0) {
-        lds->n_slow = 0;
-        // runs of consecutive flagged bins (slots are in ascending bin order)
-        unsigned nr = 0;
-        bool fits = true;
-        for (unsigned q = sb; q < se && fits; ++q) {
-          const unsigned b = lds->slot[q].bin;
-          if (nr && b == lds->rg_lo[nr - 1] + lds->rg_len[nr - 1]) {
-            lds->rg_len[nr - 1] += 1;
-          } else if (nr == 4) {
-            fits = false;
-          } else {
-            lds->rg_lo[nr] = b;
-            lds->rg_len[nr] = 1;
-            lds->rg_first[nr] = q - sb;
-            ++nr;
+      if (wid == 0) {
+        // runs of consecutive flagged bins (slots are in ascending bin order; at most 126 per sub-round):
+        // lane l looks at slots l and l + 64, a slot starts a run when its bin is not its predecessor's + 1
+        const unsigned ns = se - sb;
+        const unsigned b0 = (unsigned)lane < ns ? lds->slot[sb + lane].bin : kNoKey;
+        const unsigned b1 = (unsigned)lane + 64u < ns ? lds->slot[sb + 64u + lane].bin : kNoKey;
+        const unsigned p0 = (unsigned)__shfl_up((int)b0, 1);
+        const unsigned p1x = (unsigned)__shfl_up((int)b1, 1);
+        const unsigned p1 = lane == 0 ? (unsigned)__shfl((int)b0, 63) : p1x;
+        const unsigned long long m0 = __ballot((unsigned)lane < ns && (lane == 0 || b0 != p0 + 1u));
+        const unsigned long long m1 = __ballot((unsigned)lane + 64u < ns && b1 != p1 + 1u);
+        // lane r < 4 fills in run r (its LDS accesses proceed in parallel with the other runs')
+        const unsigned nr = (unsigned)(__popcll(m0) + __popcll(m1));
+        auto nth_start = [&](unsigned r) {                 // slot index of the r-th run start, ns past the last
+          unsigned long long w0 = m0, w1 = m1;
+          unsigned st = ns;
+          for (unsigned k = 0; k <= r; ++k) {
+            if (w0) {
+              st = (unsigned)__ffsll((long long)w0) - 1u;
+              w0 &= w0 - 1ull;
+            } else if (w1) {
+              st = 64u + (unsigned)__ffsll((long long)w1) - 1u;
+              w1 &= w1 - 1ull;
+            } else {
+              st = ns;
+            }
           }
-        }
-        for (unsigned r = 0; r < 4; ++r) {
-          if (r >= nr) {
+          return st;
+        };
+        if (lane < 4) {
+          const unsigned r = (unsigned)lane;
+          if (r >= nr || nr > 4u) {
             lds->rg_lo[r] = 0; lds->rg_len[r] = 0; lds->rg_first[r] = 0; lds->rg_succbin[r] = kNoKey; lds->rg_last[r] = 0;
           } else {
-            const unsigned lastq = lds->rg_first[r] + lds->rg_len[r] - 1;
+            const unsigned st = nth_start(r), en = nth_start(r + 1u);
+            const unsigned lastq = en - 1u;
+            lds->rg_lo[r] = lds->slot[sb + st].bin;
+            lds->rg_len[r] = en - st;
+            lds->rg_first[r] = st;
             lds->rg_last[r] = lastq;
             const unsigned nb = lds->slot[sb + lastq].next_bin;
             lds->rg_succbin[r] = nb == 0xFFFFu ? kNoKey : nb;
           }
         }
-        lds->n_rg = fits ? nr : 0u;
+        if (lane == 0) {
+          lds->n_slow = 0;
+          lds->n_rg = nr <= 4u ? nr : 0u;
+        }
       }
       if ((unsigned)tid < se - sb) lds->fill[tid] = lds->slot[sb + tid].base;     // absolute list positions
       __syncthreads();
