@@ -8,7 +8,7 @@ eager fallback here: if the library is missing, or a call fails, an exception is
 import ctypes
 import os
 import threading
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch
 
@@ -115,11 +115,16 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 # ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 _timing = None
+_timing_only = None
 
 
-def enable_timing(on: bool = True) -> None:
-    global _timing
+def enable_timing(on: bool = True, only: Optional[Sequence[str]] = None) -> None:
+    """Bracket every C-ABI call (or only the entry points named in ``only``) with HIP events on the launch
+    stream.  An event pair costs a few microseconds of stream time per call, so benchmarks instrument only
+    the kernel they report on inside their timed region."""
+    global _timing, _timing_only
     _timing = {} if on else None
+    _timing_only = None if only is None else frozenset(only)
 
 
 def drain_timing():
@@ -138,13 +143,14 @@ class _Timed:
         self.name, self.nbytes = name, (nbytes, ops)
 
     def __enter__(self):
-        if _timing is not None:
+        self.on = _timing is not None and (_timing_only is None or self.name in _timing_only)
+        if self.on:
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
 
     def __exit__(self, *exc):
-        if _timing is not None:
+        if self.on:
             self.e.record()
             _timing.setdefault(self.name, []).append((self.s, self.e, self.nbytes))
 
