@@ -52,6 +52,36 @@ def build_model(arch, device):
     return model.eval().to(device)
 
 
+def pmc_traffic_per_launch(entry):
+    """HBM bytes per C-ABI launch of ``entry`` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled on gfx950: scripts/pmc_traffic.sh ->
+    profiles/*_pmc_hbm_traffic.json), weighted by the kernel launches per step of the committed kernel
+    trace (profiles/*_per_step_summary*.csv).  Counters cannot be read from inside this process, so this is
+    the last profiled build's figure; None when the profiles are absent."""
+    import csv
+    import glob
+    prefix = {'lsq_act_quant': 'aq_', 'lsq_xnor_conv2d': 'xnor_conv_kernel', 'lsq_signw_conv2d': 'signw_conv_'}.get(entry)
+    tables = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm_traffic.json')))
+    steps = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_per_step_summary%s.csv' % ('_fpact' if entry == 'lsq_signw_conv2d' else ''))))
+    if not prefix or not tables or not steps:
+        return None
+    per_kernel = {}
+    for name, v in json.load(open(tables[-1]))['kernels'].items():       # rows: "<kernel> grid=<threads>"
+        if name.startswith(prefix):
+            per_kernel.setdefault(name.split(' grid=')[0], []).append(1e6 * (v['hbm_read_MB_corrected'] + v['hbm_write_MB']))
+    total = launches = 0.0
+    with open(steps[-1]) as f:
+        next(f)
+        for row in csv.DictReader(f):
+            kname = row['kernel']
+            match = [k for k in per_kernel if kname.startswith(k[:len(kname)]) or k.startswith(kname.split('(')[0])]
+            if match:
+                total += float(row['launches_per_step']) * sum(per_kernel[match[0]]) / len(per_kernel[match[0]])
+                launches += float(row['launches_per_step'])
+    calls = 16.0                                                      # QuantConv2d layers per forward
+    return {'bytes_per_launch': total / calls, 'source': os.path.basename(tables[-1])} if launches else None
+
+
 def cpu_baseline(arch, model, sample):
     """The oracle's whole-network forward (same algorithmic structure as the reference: sort + cumsum +
     mask + [N,K,M] cost + fp32 conv) timed on this box's host cores on a bounded sample."""
@@ -167,6 +197,11 @@ def main():
                                    'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': None}
                 if dominant == 'lsq_xnor_conv2d':
                     out['roofline']['T_binary_MAC_per_s'] = ops / (ms * 1e-3) / 1e12
+            pmc = pmc_traffic_per_launch(dominant)
+            if pmc:
+                out['roofline']['traffic'] = pmc['bytes_per_launch']
+                out['roofline']['traffic_note'] = ('HBM bytes per launch (all kernels of one call), rocprofv3 PMC passes in profiles/'
+                                                   + pmc['source'] + '; algorithmic bytes per launch = %.4g' % (nbytes / launches))
             out['roofline'].update(launches=launches, avg_launch_us=1e3 * ms / launches,
                                    measured='HIP events around every launch of this kernel inside the timed region',
                                    kernels=kern, kernels_measured='one fully instrumented step after the warm-up')
