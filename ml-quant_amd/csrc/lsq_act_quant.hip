@@ -146,9 +146,12 @@ struct SmallLds {
 
 // first sweep of a solver scheme: level-1 histogram, its scan, and the slot records handed to the
 // solve kernel through the workspace
+constexpr int kNzCap = 2048;                   // non-empty level-1 bins the balanced scan handles (2 per thread)
 struct SweepLds {
   unsigned long long hist1[L1_BINS];
   unsigned short nzlist[L1_BINS];
+  unsigned nz_r0[kNzCap];                       // sorted position / prefix sum in front of the i-th non-empty bin
+  double nz_p0[kNzCap];
   Slot1 slot[kSlotCap];
   unsigned wa[kWaves], wb[kWaves], wc[kWaves];
   double ws[kWaves];
@@ -627,6 +630,84 @@ __device__ __forceinline__ unsigned l1_scan(L* lds, const unsigned long long* hi
 #pragma unroll
     for (int u = 0; u < kBinsPerThread; ++u)
       if (cnt[u]) nzl[z++] = (unsigned short)((unsigned)kBinsPerThread * tid + u);
+  }
+  if constexpr (std::is_same<L, SweepLds>::value) {
+    // The non-empty bins sit in a few binades, i.e. in the 8-bin ranges of a few dozen threads, and the
+    // candidate test is ~100 fp64 instructions: run it over the COMPACT list instead, two non-empty bins
+    // per thread, with the prefixes handed over through LDS.
+    if (tnz <= (unsigned)kNzCap && round0 == 0u) {
+      {
+        unsigned z = enz, c = ecnt;
+        double sacc = esum;
+#pragma unroll
+        for (int u = 0; u < kBinsPerThread; ++u) {
+          if (cnt[u]) {
+            lds->nz_r0[z] = c;
+            lds->nz_p0[z] = sacc;
+            ++z;
+          }
+          c += cnt[u];
+          sacc += sum[u];
+        }
+      }
+      __syncthreads();
+      unsigned bz[2], cz[2], rz[2];
+      unsigned short nz2[2];
+      double sz[2], pz[2];
+      bool fz[2];
+      unsigned nflag = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned z = 2u * (unsigned)tid + (unsigned)e;
+        fz[e] = false;
+        bz[e] = cz[e] = rz[e] = 0;
+        nz2[e] = 0xFFFFu;
+        sz[e] = pz[e] = 0.0;
+        if (z < tnz) {
+          bz[e] = nzl[z];
+          const unsigned long long h = hist1[bz[e]];
+          cz[e] = (unsigned)(h >> 42);
+          sz[e] = bin_sum_exact(bz[e] << L1_SHIFT, cz[e], h & kLowMask);
+          rz[e] = lds->nz_r0[z];
+          pz[e] = lds->nz_p0[z];
+          const double vlo = (double)key_value(bz[e] << L1_SHIFT);
+          const double vhi = (double)key_value((bz[e] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+          double next_hi = vhi;
+          if (z + 1 < tnz) {
+            nz2[e] = nzl[z + 1];
+            next_hi = (double)key_value(((unsigned)nz2[e] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+          }
+          fz[e] = n >= 3u && may_hold_candidate(rz[e], cz[e], pz[e], sz[e], vlo, vhi, next_hi, n, total, ternary);
+          nflag += fz[e] ? 1u : 0u;
+        }
+      }
+      unsigned eflag = nflag, dummy = 0, tflag, tdummy;
+      double dzero = 0.0, tdz;
+      block_excl_scan(eflag, dummy, dzero, tflag, tdummy, tdz, lds);
+      unsigned ord = eflag;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (fz[e]) {
+          if (ord < (unsigned)kSlotCap) {
+            Slot1 sl;
+            sl.bin = (unsigned short)bz[e];
+            sl.next_bin = nz2[e];
+            sl.cnt = cz[e];
+            sl.r0 = rz[e];
+            sl.succ = kNoKey;
+            sl.base = 0;
+            sl.pad = 0;
+            sl.p0 = pz[e];
+            sl.sum = sz[e];
+            lds->slot[ord] = sl;
+          }
+          ++ord;
+        }
+      }
+      if (tid == 0) lds->total = total;
+      __syncthreads();
+      return tflag;
+    }
   }
   __syncthreads();
   unsigned my_flags = 0;
@@ -1410,6 +1491,7 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   if (tid == 0) lds->args = a;
   if (tid < LSQ_MAX_PLANES) lds->sv[tid] = tid < q ? a.scales[(long long)tid * a.N + row] : 0.f;
   __syncthreads();
+  if constexpr (HIST) LSQ_MARK(15);
   LSQ_MARK(0);
   PassOut po;
   if (a.flat) {
@@ -1420,6 +1502,7 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   }
   LSQ_MARK(1);
   const double tot = block_sum(po.sum, lds);
+  LSQ_MARK(7);
   if (a.write_scale && tid == 0) a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);
   if constexpr (HIST) {
     const unsigned n_sub = (unsigned)((a.row_elems + a.skip - 1) / a.skip);
@@ -1429,7 +1512,11 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
     __syncthreads();
     unsigned minkey = kNoKey;
     for (int w = 0; w < kWaves; ++w) minkey = min(minkey, lds->wa[w]);
+    LSQ_MARK(8);
+    LSQ_MARK(8);
     const unsigned tflag = l1_scan(lds, lds->hist1, lds->nzlist, n_sub, 0);
+    LSQ_MARK(14);
+    LSQ_MARK(14);
     unsigned char* wrow = a.ws + (long long)row * kWsRow;
     if (tid == 0) {
       RowHeader h;
@@ -1451,6 +1538,7 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
       for (int i = tid; i < L1_BINS; i += kThreads) hd[i] = lds->hist1[i];
     }
   }
+  if constexpr (HIST) LSQ_MARK(16);
   LSQ_MARK(9);
 }
 
