@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Patch version (stride 1, any padding / dilation).  Padded coordinates hp = hi + pad_h, wp = wi + pad_w
+// Patch version (any stride / padding / dilation).  Padded coordinates hp = hi + pad_h, wp = wi + pad_w
 // and the linear index L = (n*Hp + hp)*Wp + wp: output pixel (n, ho, wo) and tap (kh, kw) read
-// L = B + T with B = (n*Hp + ho)*Wp + wo and T = kh*dil_h*Wp + kw*dil_w.  The BN consecutive output
+// L = B + T with B = (n*Hp + ho*stride_h)*Wp + wo*stride_w and T = kh*dil_h*Wp + kw*dil_w.  The BN consecutive output
 // pixels of a workgroup therefore touch the contiguous range [B_first, B_last + T_max] of L -- the patch,
 // at most PLr <= 512 entries (host-side bound, multiple of 128).  Per 16-channel chunk (one MFMA k-step)
 // the workgroup
@@ -309,18 +309,20 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
 // Each wave owns a 64 x 64 tile (2 x 2 MFMA tiles): 16 MFMAs per tap against 6 fragment reads.
 constexpr int kPC = 16;                          // channels per chunk
 constexpr int kPRow = 32;                        // bytes per LDS row (16 bf16)
-constexpr int kPMaxEntries = 512;                // patch entries the LDS planes hold
-constexpr int kPlane = kPMaxEntries * kPRow;     // lo plane follows the hi plane at this offset
 constexpr int kTapGroup = 9;                     // taps whose weights are resident at a time
-constexpr int kMaxPre = 512;                     // channels per group the folded-batch-norm table holds
 
 __device__ __forceinline__ int swz(int row, int half) { return row * kPRow + ((half ^ ((row >> 3) & 1)) << 4); }
 
-template <int BM, int BN, int WM, int WN, bool MANY_TAPS>
+// PMAX: patch entries the LDS planes hold; PREMAX: channels per group the folded-batch-norm table holds.
+// Stride 1: 128 x 128 (or 64 x 256) tiles, 64 x 64 per wave, PMAX 512.  Stride 2: only every second entry of a
+// row feeds a given tap, so the same 128 pixels would need a patch twice as long: 128 x 64 tiles (64 x 32 per
+// wave), PMAX 640.
+template <int BM, int BN, int WM, int WN, int TN, int PMAX, int PREMAX, bool MANY_TAPS>
 __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp, int PLr) {
-  constexpr int TM = 2, TN = 2;
+  constexpr int TM = 2;
+  constexpr int kPMaxEntries = PMAX, kPlane = PMAX * kPRow, kMaxPre = PREMAX;
   static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-  constexpr int kItems = kPMaxEntries * 2 / 256;         // (entry, octet) items per thread, at most
+  constexpr int kItems = (kPMaxEntries * 2 + 255) / 256; // (entry, octet) items per thread, at most
   constexpr int WPARTS = 256 / BM;                       // threads per weight row
   constexpr int WTAPS = (kTapGroup + WPARTS - 1) / WPARTS;   // taps per thread and group
   __shared__ __attribute__((aligned(16))) unsigned char sP[2 * kPlane];
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
     const int n = p / HoWo;
     const int r = p - n * HoWo;
     const int ho = r / a.Wo;
-    return (n * Hp + ho) * Wp + (r - ho * a.Wo);
+    return (n * Hp + ho * a.sh) * Wp + (r - ho * a.Wo) * a.sw;
   };
   const int p0 = blockIdx.x * BN;
   const int bmin = base_of(p0);
@@ -624,16 +626,20 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
   const bool wide = a.og > 64;
   const int bm = wide ? 128 : 64;
   a.tiles_per_group = (a.og + bm - 1) / bm;
-  // stride-1 layers whose input patch fits the LDS planes take the patch kernel: 128 out-channels x 128
-  // pixels per workgroup, or 64 x 256 for narrow layers (the patch conversion is shared by more pixels)
+  // Layers whose input patch fits the LDS planes take the patch kernel.  Stride 1: 128 out-channels x 128
+  // pixels per workgroup, or 64 x 256 for narrow layers (the patch conversion is shared by more pixels);
+  // other strides: 64 pixels per workgroup (the patch of the same pixels is stride^2 times sparser).
   const int Hp = g->H + 2 * g->pad_h, Wp = g->W + 2 * g->pad_w;
-  const int pbn = wide ? 128 : 256;
-  const long long patch = pbn + ((pbn - 1) / Wo + 1) * (long long)(Wp - Wo) +
-                          ((pbn - 1) / (Ho * Wo) + 1) * (long long)(Hp - Ho) * Wp +
+  const bool unit = g->stride_h == 1 && g->stride_w == 1;
+  const int pbn = unit ? (wide ? 128 : 256) : (wide ? 64 : 128);
+  const int pmax = unit ? 512 : 640, premax = unit ? 512 : 256;
+  const long long row_gap = (long long)g->stride_h * Wp - (long long)Wo * g->stride_w;
+  const long long img_gap = ((long long)Hp - (long long)Ho * g->stride_h) * Wp;
+  const long long patch = (long long)(pbn - 1) * g->stride_w + ((pbn - 1) / Wo + 1) * (row_gap > 0 ? row_gap : 0) +
+                          ((pbn - 1) / (Ho * Wo) + 1) * (img_gap > 0 ? img_gap : 0) +
                           (long long)(g->KH - 1) * g->dil_h * Wp + (long long)(g->KW - 1) * g->dil_w + 1;
   const int PLr = (int)((patch + 127) / 128 * 128);
-  bool use_patch = g->stride_h == 1 && g->stride_w == 1 && PLr <= kPMaxEntries &&
-                   (!pre_scale || (a.cg + kPC - 1) / kPC * kPC <= kMaxPre) &&
+  bool use_patch = PLr <= pmax && (!pre_scale || (a.cg + kPC - 1) / kPC * kPC <= premax) &&
                    (long long)g->N * g->C * g->H * g->W < (1ll << 30) && (long long)g->N * Hp * Wp + PLr < (1ll << 31) &&
                    (long long)g->N * g->O * Ho * Wo < (1ll << 30);
 #ifdef LSQ_TUNE
@@ -648,10 +654,16 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
     if (use_patch) {
       dim3 grid((unsigned)((total + pbn - 1) / pbn), otiles);
       const bool many = g->KH * g->KW > kTapGroup;
-      if (wide && !many) hipLaunchKernelGGL((signw_conv_patch<128, 128, 2, 2, false>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
-      else if (wide) hipLaunchKernelGGL((signw_conv_patch<128, 128, 2, 2, true>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
-      else if (!many) hipLaunchKernelGGL((signw_conv_patch<64, 256, 1, 4, false>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
-      else hipLaunchKernelGGL((signw_conv_patch<64, 256, 1, 4, true>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);
+#define LSQ_PATCH(BM_, BN_, WM_, WN_, TN_, PM_, PRE_)                                                              \
+  do {                                                                                                             \
+    if (many) hipLaunchKernelGGL((signw_conv_patch<BM_, BN_, WM_, WN_, TN_, PM_, PRE_, true>), grid, dim3(256), 0, st, a, Hp, Wp, PLr); \
+    else hipLaunchKernelGGL((signw_conv_patch<BM_, BN_, WM_, WN_, TN_, PM_, PRE_, false>), grid, dim3(256), 0, st, a, Hp, Wp, PLr);     \
+  } while (0)
+      if (unit && wide) LSQ_PATCH(128, 128, 2, 2, 2, 512, 512);
+      else if (unit) LSQ_PATCH(64, 256, 1, 4, 2, 512, 512);
+      else if (wide) LSQ_PATCH(128, 64, 2, 2, 1, 640, 256);
+      else LSQ_PATCH(64, 128, 1, 4, 1, 640, 256);
+#undef LSQ_PATCH
     } else {
       dim3 grid((unsigned)((total + kBN - 1) / kBN), otiles);
       if (wide) hipLaunchKernelGGL((signw_conv_tiled<128, 2, 2, 2, 2>), grid, dim3(256), 0, st, a);

@@ -428,7 +428,10 @@ def test_fp_activation_sign_weight_conv_mfma(golden, ws):
     ((5, 32, 7, 7), 160, 3, 1, 1, 1, 1),      # several images per workgroup, 128-row tiles
     ((2, 16, 20, 9), 24, (5, 2), (0, 1), 1, 1, 2),   # asymmetric kernel / padding, groups
     ((1, 32, 10, 150), 32, 3, 1, 1, 1, 1),    # patch too long for LDS -> im2col kernel
-    ((2, 32, 31, 31), 48, 3, 1, 1, 2, 1),     # stride 2 -> im2col kernel
+    ((2, 32, 31, 31), 48, 3, 1, 1, 2, 1),     # stride 2: patch kernel with 64-pixel tiles
+    ((3, 64, 56, 56), 128, 3, 1, 1, 2, 1),    # the first down-sampling layer of ResNet-18 (640-entry patch)
+    ((2, 24, 17, 12), 40, 3, 1, 1, (2, 1), 1),   # anisotropic stride
+    ((1, 16, 20, 20), 16, 3, 0, 1, 3, 1),     # stride larger than the dilated kernel reach, no padding
 ])
 def test_fp_activation_conv_kernel_selection_geometries(shape, cout, k, pad, dil, stride, groups):
     """Both MFMA kernels (stride-1 LDS-resident patch, im2col tiles) against the oracle on geometries that
