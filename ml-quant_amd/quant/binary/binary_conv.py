@@ -205,6 +205,10 @@ class QuantConv2d(nn.Conv2d):
             # halo words must be zero; the kernels only ever write the interior
             ws = (torch.zeros((k * words,), dtype=torch.int64, device=x.device),
                   torch.empty((k, n), dtype=torch.float32, device=x.device))
+            # one plane workspace per input shape; serving with many batch sizes must not grow without bound
+            stale = [kk for kk in self._hip_cache if isinstance(kk, tuple) and kk[0] == 'act']
+            for kk in stale[:max(0, len(stale) - 3)]:
+                del self._hip_cache[kk]
             self._hip_cache[key] = ws
         planes, scales = ws
         forced = xq.eval_scales(n)
