@@ -1,24 +1,24 @@
 // Activation quantization for gfx950: clamp -> per-row optimal-scale solve -> packed sign planes.
 //
-// One 1024-thread workgroup owns one row (one sample, quantization.py:77) from the first
-// byte read to the last word written, so every cross-pass hand-off stays inside a CU (LDS +
-// registers); rows are independent, so a batch of N rows is a grid of N workgroups.
+// One 1024-thread workgroup owns one row (one sample, quantization.py:77) in every kernel of the sequence
+// (histogram sweep -> solve -> one sweep per further plane); rows are independent, so a batch of N rows is
+// a grid of N workgroups.  The kernels are separate on purpose: each gets its own register allocation
+// (fused into one kernel, the rarely used paths pushed the streaming loops into scratch).
 //
-// The optimal-v1 solve (quant/binary/optimal.py:41-155) never sorts.  It is a three-level
-// radix select over the IEEE bit pattern of |x| (12 + 10 + 9 bits).  Each histogram bin
-// accumulates, with ONE 64-bit LDS atomic per element, its count and the exact integer sum
-// of the low key bits; within a bin the exponent is fixed, so value = 2^e * mantissa is
-// linear in those bits and the bin's sum, hence rank and prefix sum at every bin boundary,
-// is exact.  m1(i), m2(i) of optimal.py:66-74 are monotone in the sorted position i, so only
-// bins whose value range can intersect them are refined (typically 2-4 of 4096); their keys
-// are gathered once into LDS and levels 2 and 3 run from LDS.  Level 3 bins are single
-// keys: candidates are tested exactly (fp64) and their least-squares cost is evaluated in
-// closed form from the prefix sums, replacing the reference's [N,K,M] broadcast
-// (optimal.py:31-38).  oracle/radix_select_model.py is the host model of this file.
+// The optimal-v1 solve (quant/binary/optimal.py:41-155) never sorts.  It is a radix select over the IEEE
+// bit pattern of |x|: a 13-bit level-1 histogram over the whole sub-sample, then, for the few bins that can
+// hold a candidate, an 8-bit level per wave (block-level fall-back: 10 + 8 bits).  Each histogram bin
+// accumulates, with ONE 64-bit LDS atomic per element, its count and the exact integer sum of the low key
+// bits; within a bin the exponent is fixed, so value = 2^e * mantissa is linear in those bits and the
+// bin's sum, hence rank and prefix sum at every bin boundary, is exact.  m1(i), m2(i) of optimal.py:66-74
+// are monotone in the sorted position i, so only bins whose value range can intersect them are refined
+// (typically 10-25 of 8192); their keys are gathered once into LDS.  Candidates are tested exactly (fp64)
+// and their least-squares cost is evaluated in closed form from the prefix sums, replacing the reference's
+// [N,K,M] broadcast (optimal.py:31-38).  oracle/radix_select_model.py is the host model of this file.
 //
-// Memory traffic per row of M floats: pass 0 reads M (plane 0 + level-1 histogram), the
-// gather pass touches the sub-sample (every line of the row at skip=3), pass 1 reads M
-// (plane 1 + v2).  Writes are M/32 bytes per plane.  Algorithmic minimum is one read of M.
+// Memory traffic per row of M floats: the histogram sweep reads M (plane 0 + level-1 histogram), the
+// solve's gather reads M again (the sub-sample touches every line at skip = 3), the plane-1 sweep reads M
+// (plane 1 + v2).  Writes are M/8 bytes per plane.  Algorithmic minimum is one read of M.
 
 #include <type_traits>
 
@@ -596,7 +596,7 @@ __device__ __forceinline__ void for_each_row_key(const Args& a, const float* __r
 // The solve.  On entry hist1 holds the level-1 histogram of the n sub-sampled keys.  The phases are
 // separate non-inlined functions on purpose: each gets its own register allocation, so the rarely
 // used block-level path cannot push the streaming sweeps of the kernel into scratch.
-// level 1: scan the 4096-bin histogram (4 bins per thread), flag bins that may hold a candidate, and
+// level 1: scan the 8192-bin histogram (8 bins per thread), flag bins that may hold a candidate, and
 // write a slot record for the flagged bins with ordinal in [round0, round0 + kSlotCap)
 template <class L>
 __device__ __forceinline__ unsigned l1_scan(L* lds, const unsigned long long* hist1, unsigned short* nzl, unsigned n,
