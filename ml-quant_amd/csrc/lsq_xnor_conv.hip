@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
   const int o0 = grp * a.og + t * OT;
   const int o_valid = min(OT, a.og - t * OT);
   const int HoWo = a.Ho * a.Wo;
-  const int n = (int)(pix / HoWo);
+  // (a 64-bit integer division is ~100 VALU instructions: take it only for tensors past 2^31 pixels)
+  const int n = total <= 0x7FFFFFFFll ? (int)((unsigned)pix / (unsigned)HoWo) : (int)(pix / HoWo);
   const int r = (int)(pix - (long long)n * HoWo);
-  const int ho = r / a.Wo, wo = r - ho * a.Wo;
+  const int ho = (int)((unsigned)r / (unsigned)a.Wo), wo = r - ho * a.Wo;
   const long long HpWp = (long long)a.Hp * a.Wp;
 
   int acc[KX][OT];
@@ -205,11 +206,14 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
 #pragma unroll
   for (int o = 0; o < OT; ++o) {
     if (o < o_valid) {
-      float v = 0.f;
+      // (b * s) = full + corr - 2 * popcount, per plane; y = ws * sum_p xs_p * (b_p * s) + bias: one integer
+      // op, one convert and one fma per plane, one fma for scale + bias
+      const int fc = full + corr[o];
+      float v = xs[0] * (float)(fc - (acc[0][o] << 1));
 #pragma unroll
-      for (int p = 0; p < KX; ++p) v += xs[p] * (float)(full - 2 * acc[p][o] + corr[o]);
-      v *= a.wscale[o0 + o];
-      float out = (a.accumulate ? yp[(long long)o * HoWo] : (a.bias ? a.bias[o0 + o] : 0.f)) + v;
+      for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)(fc - (acc[p][o] << 1)), v);
+      const float base = a.accumulate ? yp[(long long)o * HoWo] : (a.bias ? a.bias[o0 + o] : 0.f);
+      float out = fmaf(v, a.wscale[o0 + o], base);
       if (a.final_pass) {        // fused block epilogue (non-linearity and shortcut adds of resnet.py:182-190)
         if (want_pre) out += rv[o];
         if (a.relu) out = fmaxf(out, 0.f);
