@@ -11,7 +11,6 @@ from typing import Tuple
 
 import torch
 
-from quant.binary.ste import binary_sign
 
 
 def _prefix(matrix: torch.Tensor):
