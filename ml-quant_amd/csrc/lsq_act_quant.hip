@@ -1290,59 +1290,10 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       for (unsigned si = 0; si < nslot; ++si) best = resolve_slot_block(lds, xrow, n, si, true, best);
     }
   } else if (tflag) {
-    // split the flagged bins into sub-rounds by gathered-key capacity.  Usual case: everything fits one
-    // round -- wave 0 turns the counts into list offsets with a scan; otherwise one lane splits greedily.
-    if (wid == 0) {
-      unsigned cq[4], lane_tot = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned q = (unsigned)lane * 4u + (unsigned)u;
-        cq[u] = q < tflag ? lds->slot[q].cnt : 0u;
-        lane_tot += cq[u];
-      }
-      const unsigned incl = wave_incl_scan(lane_tot);
-      const unsigned all = (unsigned)__shfl((int)incl, 63);
-      if (all <= (unsigned)kListExt && tflag <= (unsigned)kSubSlots) {
-        unsigned acc = incl - lane_tot;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned q = (unsigned)lane * 4u + (unsigned)u;
-          if (q < tflag) lds->slot[q].base = acc;
-          acc += cq[u];
-        }
-        if (lane == 0) {
-          lds->sub_begin[0] = 0;
-          lds->sub_begin[1] = (unsigned short)tflag;
-          lds->n_sub = 1;
-        }
-      } else if (lane == 0) {
-        unsigned ns = 0, begin = 0, acc = 0;
-        for (unsigned q = 0; q < tflag; ++q) {
-          const unsigned c1 = lds->slot[q].cnt;
-          if (q > begin && (acc + c1 > (unsigned)kListExt || q - begin >= (unsigned)kSubSlots)) {
-            lds->sub_begin[ns++] = (unsigned short)begin;
-            begin = q;
-            acc = 0;
-          }
-          lds->slot[q].base = acc;
-          acc += c1;
-        }
-        lds->sub_begin[ns++] = (unsigned short)begin;
-        lds->sub_begin[ns] = (unsigned short)tflag;
-        lds->n_sub = ns;
-      }
-    }
-    __syncthreads();
-    const unsigned n_sub = lds->n_sub;
-    for (unsigned sr = 0; sr < n_sub; ++sr) {
-      const unsigned sb = lds->sub_begin[sr], se = lds->sub_begin[sr + 1];
-      if (sr) __syncthreads();                         // the previous sub-round's list and slots are done with
-      if (se - sb == 1u && lds->slot[sb].cnt > (unsigned)kListExt) {
-        if (tid == 0) lds->dbg_rowpass += 1;
-        best = resolve_slot_block(lds, xrow, n, sb, true, best);              // one huge bin: histogram straight from the row
-        continue;
-      }
-      if (wid == 0) {
+    // wave 0 prepares a sub-round: runs of consecutive flagged bins for the gather's membership test and
+    // the list offsets of the slots (fill[] starts at the segment base so that the gather's returning
+    // atomic yields the absolute list position)
+    auto prepare_round = [&](unsigned sb, unsigned se) {
         // runs of consecutive flagged bins (slots are in ascending bin order; at most 126 per sub-round):
         // lane l looks at slots l and l + 64, a slot starts a run when its bin is not its predecessor's + 1
         const unsigned ns = se - sb;
@@ -1390,9 +1341,67 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
           lds->n_slow = 0;
           lds->n_rg = nr <= 4u ? nr : 0u;
         }
+        for (unsigned q = (unsigned)lane; q < se - sb; q += kWave) lds->fill[q] = lds->slot[sb + q].base;
+    };
+    // split the flagged bins into sub-rounds by gathered-key capacity.  Usual case: everything fits one
+    // round -- wave 0 turns the counts into list offsets with a scan; otherwise one lane splits greedily.
+    if (wid == 0) {
+      unsigned cq[4], lane_tot = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned q = (unsigned)lane * 4u + (unsigned)u;
+        cq[u] = q < tflag ? lds->slot[q].cnt : 0u;
+        lane_tot += cq[u];
       }
-      if ((unsigned)tid < se - sb) lds->fill[tid] = lds->slot[sb + tid].base;     // absolute list positions
-      __syncthreads();
+      const unsigned incl = wave_incl_scan(lane_tot);
+      const unsigned all = (unsigned)__shfl((int)incl, 63);
+      if (lane == 0) lds->dbg_gathered = all;          // diagnostics: keys of all flagged bins
+      if (all <= (unsigned)kListExt && tflag <= (unsigned)kSubSlots) {
+        unsigned acc = incl - lane_tot;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned q = (unsigned)lane * 4u + (unsigned)u;
+          if (q < tflag) lds->slot[q].base = acc;
+          acc += cq[u];
+        }
+        if (lane == 0) {
+          lds->sub_begin[0] = 0;
+          lds->sub_begin[1] = (unsigned short)tflag;
+          lds->n_sub = 1;
+        }
+      } else if (lane == 0) {
+        unsigned ns = 0, begin = 0, acc = 0;
+        for (unsigned q = 0; q < tflag; ++q) {
+          const unsigned c1 = lds->slot[q].cnt;
+          if (q > begin && (acc + c1 > (unsigned)kListExt || q - begin >= (unsigned)kSubSlots)) {
+            lds->sub_begin[ns++] = (unsigned short)begin;
+            begin = q;
+            acc = 0;
+          }
+          lds->slot[q].base = acc;
+          acc += c1;
+        }
+        lds->sub_begin[ns++] = (unsigned short)begin;
+        lds->sub_begin[ns] = (unsigned short)tflag;
+        lds->n_sub = ns;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // this wave reads what its lanes just wrote
+      prepare_round(lds->sub_begin[0], lds->sub_begin[1]);         // first (usually only) sub-round: no extra barrier
+    }
+    __syncthreads();
+    const unsigned n_sub = lds->n_sub;
+    for (unsigned sr = 0; sr < n_sub; ++sr) {
+      const unsigned sb = lds->sub_begin[sr], se = lds->sub_begin[sr + 1];
+      if (sr) {
+        __syncthreads();                               // the previous sub-round's list and slots are done with
+        if (wid == 0) prepare_round(sb, se);
+        __syncthreads();
+      }
+      if (se - sb == 1u && lds->slot[sb].cnt > (unsigned)kListExt) {
+        if (tid == 0) lds->dbg_rowpass += 1;
+        best = resolve_slot_block(lds, xrow, n, sb, true, best);              // one huge bin: histogram straight from the row
+        continue;
+      }
       if (lds->n_rg == 0u) {            // > 4 runs: membership through the role table instead
         for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->role)[i] = 0u;
         __syncthreads();
@@ -1433,10 +1442,7 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       __syncthreads();
       LSQ_MARK(5);
       const unsigned n_slow = lds->n_slow;
-      if (tid == 0) {
-        lds->dbg_slow += n_slow;
-        for (unsigned q = sb; q < se; ++q) lds->dbg_gathered += lds->slot[q].cnt;
-      }
+      if (tid == 0) lds->dbg_slow += n_slow;
       for (unsigned q = 0; q < n_slow; ++q) best = resolve_slot_block(lds, xrow, n, lds->slow[q], false, best);
     }
   }
@@ -1465,12 +1471,18 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
     o.value = __shfl_xor(best.value, d);
     if (better(o, best)) best = o;
   }
-  __syncthreads();
   if (lane == 0) lds->wbest[wid] = best;
   __syncthreads();
-  Best r = lds->wbest[0];
-  for (int w = 1; w < kWaves; ++w)
-    if (better(lds->wbest[w], r)) r = lds->wbest[w];
+  // (only thread 0 uses the result: wave 0 reduces the 16 wave minima with four more shuffles)
+  Best r = lds->wbest[lane & (kWaves - 1)];
+#pragma unroll
+  for (int d = kWaves / 2; d > 0; d >>= 1) {
+    Best o;
+    o.cost = __shfl_xor(r.cost, d);
+    o.order = __shfl_xor(r.order, d);
+    o.value = __shfl_xor(r.value, d);
+    if (better(o, r)) r = o;
+  }
   return r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
 }
 
