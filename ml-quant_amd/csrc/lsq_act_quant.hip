@@ -1513,18 +1513,27 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
     po = pack_pass<VEC, HIST, QM>(lds, xrow, prow, q);
   }
   LSQ_MARK(1);
-  const double tot = block_sum(po.sum, lds);
+  // row sum (and, for the histogram sweep, the smallest key) in one LDS exchange
+  double tot = 0.0;
+  unsigned minkey = kNoKey;
+  {
+    const double wsum = wave_sum(po.sum);
+    const unsigned wmin = HIST ? wave_min(po.minkey) : kNoKey;
+    __syncthreads();
+    if ((tid & 63) == 0) {
+      lds->ws[tid >> 6] = wsum;
+      if constexpr (HIST) lds->wa[tid >> 6] = wmin;
+    }
+    __syncthreads();
+    for (int w = 0; w < kWaves; ++w) {
+      tot += lds->ws[w];
+      if constexpr (HIST) minkey = min(minkey, lds->wa[w]);
+    }
+  }
   LSQ_MARK(7);
   if (a.write_scale && tid == 0) a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);
   if constexpr (HIST) {
     const unsigned n_sub = (unsigned)((a.row_elems + a.skip - 1) / a.skip);
-    const unsigned mk = wave_min(po.minkey);
-    __syncthreads();
-    if ((tid & 63) == 0) lds->wa[tid >> 6] = mk;
-    __syncthreads();
-    unsigned minkey = kNoKey;
-    for (int w = 0; w < kWaves; ++w) minkey = min(minkey, lds->wa[w]);
-    LSQ_MARK(8);
     LSQ_MARK(8);
     const unsigned tflag = l1_scan(lds, lds->hist1, lds->nzlist, n_sub, 0);
     LSQ_MARK(14);
