@@ -46,7 +46,8 @@ constexpr int kSlotCap = 256;                  // flagged level-1 bins held as s
 constexpr int kSubSlots = 126;                 // slots gathered per sub-round (role table bytes)
 constexpr int kSeg3 = 8;                       // level-2 bins refined per level-3 pass
 constexpr int kListExt = 22528;                // gathered keys held in LDS (88 KB)
-constexpr int kWaveSub = 256, kWaveShift = 10; // wave-level refinement: key bits [17:10]
+constexpr int kWaveSub = 256;                  // wave-level refinement: at most 256 sub-bins (key bits [17:10])
+constexpr int kSmallSeg = 1024;                // segments up to this many keys use 64 sub-bins (<= 64 keys each, typically 16)
 constexpr unsigned kNoKey = 0xFFFFFFFFu;
 constexpr unsigned long long kOne = 1ull << 42;          // count field of a histogram word
 constexpr unsigned long long kLowMask = kOne - 1;
@@ -937,7 +938,13 @@ struct WaveOut {
   int ok;
 };
 
+// PER sub-bins per lane: 4 (256 sub-bins of key bits [17:10]) or, for segments of at most kSmallSeg keys, 1
+// (64 sub-bins of bits [17:12]: a quarter of the candidate tests and scan work per slot)
+template <int PER>
 __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n, unsigned si, Best best) {
+  constexpr int kSub = 64 * PER;                           // sub-bins
+  constexpr int kSubBits = PER == 4 ? 8 : 6;
+  constexpr int kShift = L1_SHIFT - kSubBits;              // low key bits below the sub-bin index
   const float* xrow = nullptr;
   const Args& a = lds->args;
   unsigned* const list = lds->k.list;          // kListExt keys (runs on into hist1)
@@ -955,26 +962,26 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
   LSQ_MARK(20);
   LSQ_NOTE(25, seg_n);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) h[lane * 4 + u] = 0ull;
+  for (int u = 0; u < PER; ++u) h[lane * PER + u] = 0ull;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (unsigned i = lane; i < seg_n; i += kWave) {
     const unsigned key = seg[i];
-    atomicAdd(&h[(key >> kWaveShift) & (kWaveSub - 1)], kOne | (unsigned long long)(key & ((1u << kWaveShift) - 1u)));
+    atomicAdd(&h[(key >> kShift) & (kSub - 1)], kOne | (unsigned long long)(key & ((1u << kShift) - 1u)));
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   LSQ_MARK(21);
-  unsigned c[4], lane_cnt = 0, first_sub = kNoKey;
-  double sm[4], lane_sum = 0.0;
+  unsigned c[PER], lane_cnt = 0, first_sub = kNoKey;
+  double sm[PER], lane_sum = 0.0;
 #pragma unroll
-  for (int u = 3; u >= 0; --u) {
-    const unsigned long long hv = h[lane * 4 + u];
+  for (int u = PER - 1; u >= 0; --u) {
+    const unsigned long long hv = h[lane * PER + u];
     c[u] = (unsigned)(hv >> 42);
-    const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
+    const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * PER + u) << kShift);
     sm[u] = c[u] ? bin_sum_exact(hi_key, c[u], hv & kLowMask) : 0.0;
-    if (c[u]) first_sub = (unsigned)(lane * 4 + u);
+    if (c[u]) first_sub = (unsigned)(lane * PER + u);
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < PER; ++u) {
     lane_cnt += c[u];
     lane_sum += sm[u];
   }
@@ -991,32 +998,32 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
     const unsigned up1 = __shfl_down(sfx, 1);
     after = lane < 63 ? up1 : kNoKey;
   }
-  unsigned nsub[4], r0s[4];
-  double p0s[4];
-  bool fl[4];
+  unsigned nsub[PER], r0s[PER];
+  double p0s[PER];
+  bool fl[PER];
   {
     unsigned cur = after;
 #pragma unroll
-    for (int u = 3; u >= 0; --u) {
+    for (int u = PER - 1; u >= 0; --u) {
       nsub[u] = cur;
-      if (c[u]) cur = (unsigned)(lane * 4 + u);
+      if (c[u]) cur = (unsigned)(lane * PER + u);
     }
     unsigned rr = s1.r0 + (ic - lane_cnt);
     double pp = s1.p0 + (is - lane_sum);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PER; ++u) {
       r0s[u] = rr;
       p0s[u] = pp;
       rr += c[u];
       pp += sm[u];
       fl[u] = false;
       if (c[u]) {
-        const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * 4 + u) << kWaveShift);
+        const unsigned hi_key = (s1_bin << L1_SHIFT) | ((unsigned)(lane * PER + u) << kShift);
         const double vlo = (double)key_value(hi_key);
-        const double vhi = (double)key_value(hi_key | ((1u << kWaveShift) - 1u));
+        const double vhi = (double)key_value(hi_key | ((1u << kShift) - 1u));
         double next_hi = vhi;
         if (nsub[u] != kNoKey)
-          next_hi = (double)key_value((s1_bin << L1_SHIFT) | (nsub[u] << kWaveShift) | ((1u << kWaveShift) - 1u));
+          next_hi = (double)key_value((s1_bin << L1_SHIFT) | (nsub[u] << kShift) | ((1u << kShift) - 1u));
         else if (succ_b != kNoKey)
           next_hi = (double)key_value(succ_b);
         fl[u] = may_hold_candidate(r0s[u], c[u], p0s[u], sm[u], vlo, vhi, next_hi, n, total, ternary);
@@ -1025,26 +1032,25 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
   }
   bool ok = true;
   LSQ_MARK(22);
-  LSQ_NOTE(26, __popcll(__ballot(fl[0])) + __popcll(__ballot(fl[1])) + __popcll(__ballot(fl[2])) + __popcll(__ballot(fl[3])));
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < PER; ++u) {
     unsigned long long todo = __ballot(fl[u]);
     while (todo) {                               // wave-uniform loop over flagged sub-bins
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1ull;
-      const unsigned sub = (unsigned)(src * 4 + u);
+      const unsigned sub = (unsigned)(src * PER + u);
       const unsigned cc = __shfl(c[u], src);
       const unsigned rs = __shfl(r0s[u], src);
       const double ps = __shfl(p0s[u], src);
       const unsigned ns = __shfl(nsub[u], src);
-      const unsigned pref = (s1_bin << 8) | sub;
-      const unsigned npref = ns != kNoKey ? ((s1_bin << 8) | ns) : kNoKey;
+      const unsigned pref = (s1_bin << kSubBits) | sub;
+      const unsigned npref = ns != kNoKey ? ((s1_bin << kSubBits) | ns) : kNoKey;
       // one sweep of the segment: this sub-bin's keys (first 64) + its min/max + successor key
       unsigned pos = 0, succ_l = kNoKey, kmin = kNoKey, kmax = 0u;
       for (unsigned i0 = 0; i0 < seg_n; i0 += kWave) {
         const unsigned i = i0 + lane;
         const unsigned key = i < seg_n ? seg[i] : kNoKey;
-        const unsigned pk = key >> kWaveShift;
+        const unsigned pk = key >> kShift;
         const bool mine = i < seg_n && pk == pref;
         const unsigned long long mm = __ballot(mine);
         if (mine) {
@@ -1433,7 +1439,8 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       }
       LSQ_MARK(4);
       for (unsigned si = sb + (unsigned)wid; si < se; si += kWaves) {
-        const WaveOut wo = resolve_slot_wave(lds, n, si, best);
+        const WaveOut wo = lds->slot[si].cnt <= (unsigned)kSmallSeg ? resolve_slot_wave<1>(lds, n, si, best)
+                                                                    : resolve_slot_wave<4>(lds, n, si, best);
         best = wo.best;
         if (!wo.ok) {
           if (lane == 0) lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)si;
