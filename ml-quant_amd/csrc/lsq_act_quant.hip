@@ -27,11 +27,16 @@
 namespace lsq {
 #ifdef LSQ_PHASE_CLOCKS
 __device__ long long g_phase_clocks[32];
+__device__ long long g_wave_stats[16][4];       // block 0: cycles in the wave path, slots, flagged sub-bins, ranked keys
 #define LSQ_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)clock64(); } while (0)
 #define LSQ_NOTE(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)(v); } while (0)
+#define LSQ_WSTAT(k, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_wave_stats[threadIdx.x >> 6][k] += (long long)(v); } while (0)
+#define LSQ_WSTAT0() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 4; ++k_) g_wave_stats[threadIdx.x >> 6][k_] = 0; } while (0)
 #else
 #define LSQ_MARK(i) do {} while (0)
 #define LSQ_NOTE(i, v) do {} while (0)
+#define LSQ_WSTAT(k, v) do {} while (0)
+#define LSQ_WSTAT0() do {} while (0)
 #endif
 namespace {
 
@@ -92,6 +97,16 @@ struct Slot1 {
   double p0, sum;
 };
 
+// one flagged sub-bin of a slot, queued by the wave that scanned the slot and resolved by whichever wave is
+// free: the 16 waves then share the expensive part instead of one wave walking all sub-bins of its slot
+struct SubTask {
+  unsigned short slot, sub;      // slot index, sub-bin index inside the level-1 bin
+  unsigned short bits, pad;      // sub-bin index width (6 or 8)
+  unsigned cc, rs, ns;           // keys in the sub-bin, sorted position in front of it, next non-empty sub-bin
+  double ps;                     // prefix sum in front of it
+};
+constexpr int kTaskCap = (L1_BINS * 2) / (int)sizeof(SubTask);   // what the role table's bytes hold (682)
+
 struct Seg3 {
   unsigned pref, next_pref, cnt, r0;
   double p0;
@@ -118,7 +133,10 @@ struct SolverLds {
   } u;
   unsigned wkeys[kWaves][kWave];
   unsigned short nzlist[L2_BINS];                      // block path, level 2
-  unsigned short role[L1_BINS];                        // low byte: 1 + gather slot; high byte: 1 + successor slot
+  union {
+    unsigned short role[L1_BINS];                      // gather: low byte 1 + gather slot, high byte 1 + successor slot
+    SubTask task[kTaskCap];                            // wave path, after the gather
+  };
   Slot1 slot[kSlotCap];
   unsigned fill[kSubSlots];
   unsigned short sub_begin[kSlotCap + 2];
@@ -130,7 +148,7 @@ struct SolverLds {
   double ws[kWaves];
   Best wbest[kWaves];
   // scalars
-  unsigned n_sub, n_cand, n_slow, blk_succ;
+  unsigned n_sub, n_cand, n_slow, blk_succ, n_task;
   unsigned dbg_slow, dbg_gathered, dbg_rowpass;   // diagnostics written back to the row header
   unsigned rg_lo[4], rg_len[4], rg_first[4], rg_succbin[4], rg_last[4], n_rg;   // runs of consecutive flagged bins
   unsigned minkey;
@@ -958,7 +976,6 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
   const unsigned* const seg = list + s1.base;
   const unsigned seg_n = s1.cnt;
   unsigned long long* const h = lds->u.whist[wid];
-  unsigned* const wk = lds->wkeys[wid];
   LSQ_MARK(20);
   LSQ_NOTE(25, seg_n);
 #pragma unroll
@@ -1030,103 +1047,137 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
       }
     }
   }
+  // queue the flagged sub-bins
   bool ok = true;
   LSQ_MARK(22);
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    unsigned long long todo = __ballot(fl[u]);
-    while (todo) {                               // wave-uniform loop over flagged sub-bins
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
-      const unsigned sub = (unsigned)(src * PER + u);
-      const unsigned cc = __shfl(c[u], src);
-      const unsigned rs = __shfl(r0s[u], src);
-      const double ps = __shfl(p0s[u], src);
-      const unsigned ns = __shfl(nsub[u], src);
-      const unsigned pref = (s1_bin << kSubBits) | sub;
-      const unsigned npref = ns != kNoKey ? ((s1_bin << kSubBits) | ns) : kNoKey;
-      // one sweep of the segment: this sub-bin's keys (first 64) + its min/max + successor key
-      unsigned pos = 0, succ_l = kNoKey, kmin = kNoKey, kmax = 0u;
-      for (unsigned i0 = 0; i0 < seg_n; i0 += kWave) {
-        const unsigned i = i0 + lane;
-        const unsigned key = i < seg_n ? seg[i] : kNoKey;
-        const unsigned pk = key >> kShift;
-        const bool mine = i < seg_n && pk == pref;
-        const unsigned long long mm = __ballot(mine);
-        if (mine) {
-          const unsigned at = pos + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
-          if (at < (unsigned)kWave) wk[at] = key;
-          kmin = min(kmin, key);
-          kmax = max(kmax, key);
-        }
-        pos += (unsigned)__popcll(mm);
-        if (i < seg_n && pk == npref) succ_l = min(succ_l, key);
+    if (fl[u]) {
+      const unsigned at = atomicAdd(&lds->n_task, 1u);
+      if (at < (unsigned)kTaskCap) {
+        SubTask tk;
+        tk.slot = (unsigned short)si;
+        tk.sub = (unsigned short)(lane * PER + u);
+        tk.bits = (unsigned short)kSubBits;
+        tk.pad = 0;
+        tk.cc = c[u];
+        tk.rs = r0s[u];
+        tk.ns = nsub[u];
+        tk.ps = p0s[u];
+        lds->task[at] = tk;
+      } else {
+        ok = false;                              // (never seen: > 682 flagged sub-bins) block path for the slot
       }
-      const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : succ_b;
-      const double succ_v = succ_k != kNoKey ? (double)key_value(succ_k) : INFINITY;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (cc > (unsigned)kWave) {
-        kmin = wave_min(kmin);
-        kmax = ~wave_min(~kmax);
-        if (kmin != kmax) {
-          ok = false;                            // many distinct keys in one sub-bin: block path
-          continue;
-        }
-        // a run of cc equal keys (saturated clamp value, exact zeros, constant rows)
-        const double v = (double)key_value(kmin);
-        if (run_has_candidate(v, cc, rs, ps, succ_v, n, total, ternary)) {
-          Best cb;
-          cb.cost = cost_of(v, rs, ps, cc, n, total, ternary);
-          cb.order = rs;
-          cb.value = key_value(kmin);
-          if (better(cb, best)) best = cb;
-          if (lane == 0) atomicAdd(&lds->n_cand, 1u);
-        }
-        continue;
-      }
-      const bool act = (unsigned)lane < cc;
-      const unsigned key = act ? wk[lane] : kNoKey;
-      unsigned rank = 0, below = 0, eq = 0;
-      double bsum = 0.0, psum = 0.0;
-      for (unsigned j = 0; j < cc; ++j) {
-        const unsigned kj = __shfl(key, (int)j);
-        const double vj = (double)key_value(kj);
-        const bool lt = kj < key, e = kj == key;
-        below += lt ? 1u : 0u;
-        eq += e ? 1u : 0u;
-        if (lt) bsum += vj;
-        if (lt || (e && j <= (unsigned)lane)) psum += vj;
-        if (lt || (e && j < (unsigned)lane)) ++rank;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (act) wk[rank] = key;                   // sorted order
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      bool cand = false;
-      if (act) {
-        const unsigned nk = rank + 1u < cc ? wk[rank + 1u] : succ_k;
-        const double v = (double)key_value(key);
-        const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
-        const long long i = (long long)rs + rank;
-        cand = i >= 1 && i <= (long long)n - 2 &&
-               position_is_candidate(v, nv, (double)(i + 1), ps + psum, (double)n, total, ternary);
-        if (cand) {
-          Best cb;
-          cb.cost = cost_of(v, rs + below, ps + bsum, eq, n, total, ternary);
-          cb.order = rs + below;
-          cb.value = key_value(key);
-          if (better(cb, best)) best = cb;
-        }
-      }
-      const unsigned long long firsts = __ballot(cand && below == rank);
-      if (lane == 0 && firsts) atomicAdd(&lds->n_cand, (unsigned)__popcll(firsts));
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
   LSQ_MARK(23);
   WaveOut wo;
   wo.best = best;
-  wo.ok = ok ? 1 : 0;
+  wo.ok = __ballot(!ok) == 0ull ? 1 : 0;
   return wo;
+}
+
+// phase 2 of the wave path: one flagged sub-bin.  Returns false when the sub-bin holds more than 64
+// distinct keys (the slot then goes to the block path).
+__device__ __forceinline__ bool resolve_task_wave(SolverLds* lds, unsigned n, const SubTask tk, Best& best) {
+  const Args& a = lds->args;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool ternary = a.ternary != 0;
+  const double total = lds->total;
+  const Slot1 s1 = lds->slot[tk.slot];
+  const unsigned s1_bin = s1.bin, succ_b = s1.succ;
+  const unsigned* const seg = lds->k.list + s1.base;
+  const unsigned seg_n = s1.cnt;
+  unsigned* const wk = lds->wkeys[wid];
+  const unsigned kSubBits = tk.bits, kShift = (unsigned)L1_SHIFT - kSubBits;
+  const unsigned sub = tk.sub, cc = tk.cc, rs = tk.rs, ns = tk.ns;
+  const double ps = tk.ps;
+  LSQ_WSTAT(2, 1);
+  LSQ_WSTAT(3, cc);
+  const unsigned pref = (s1_bin << kSubBits) | sub;
+  const unsigned npref = ns != kNoKey ? ((s1_bin << kSubBits) | ns) : kNoKey;
+  // one sweep of the segment: this sub-bin's keys (first 64) + its min/max + successor key
+  unsigned pos = 0, succ_l = kNoKey, kmin = kNoKey, kmax = 0u;
+  for (unsigned i0 = 0; i0 < seg_n; i0 += kWave) {
+    const unsigned i = i0 + lane;
+    const unsigned key = i < seg_n ? seg[i] : kNoKey;
+    const unsigned pk = key >> kShift;
+    const bool mine = i < seg_n && pk == pref;
+    const unsigned long long mm = __ballot(mine);
+    if (mine) {
+      const unsigned at = pos + (unsigned)__popcll(mm & ((1ull << lane) - 1ull));
+      if (at < (unsigned)kWave) wk[at] = key;
+      kmin = min(kmin, key);
+      kmax = max(kmax, key);
+    }
+    pos += (unsigned)__popcll(mm);
+    if (i < seg_n && pk == npref) succ_l = min(succ_l, key);
+  }
+  const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : succ_b;
+  const double succ_v = succ_k != kNoKey ? (double)key_value(succ_k) : INFINITY;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (cc > (unsigned)kWave) {
+    kmin = wave_min(kmin);
+    kmax = ~wave_min(~kmax);
+    if (kmin != kmax) return false;              // many distinct keys in one sub-bin: block path
+    // a run of cc equal keys (saturated clamp value, exact zeros, constant rows)
+    const double v = (double)key_value(kmin);
+    if (run_has_candidate(v, cc, rs, ps, succ_v, n, total, ternary)) {
+      Best cb;
+      cb.cost = cost_of(v, rs, ps, cc, n, total, ternary);
+      cb.order = rs;
+      cb.value = key_value(kmin);
+      if (better(cb, best)) best = cb;
+      if (lane == 0) atomicAdd(&lds->n_cand, 1u);
+    }
+    return true;
+  }
+  const bool act = (unsigned)lane < cc;
+  const unsigned key = act ? wk[lane] : kNoKey;
+  unsigned rank = 0, below = 0, eq = 0;
+  double bsum = 0.0, psum = 0.0;
+  // four shuffles in flight per step (a shuffle is an LDS round trip; one per iteration made the loop a
+  // latency chain of ~240 cycles per key).  Lanes >= cc hold kNoKey, which no live key is below or equal
+  // to, so the padded iterations change nothing.
+  for (unsigned j0 = 0; j0 < cc; j0 += 4u) {
+    unsigned kj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kj[q] = (unsigned)__shfl((int)key, (int)((j0 + (unsigned)q) & 63u));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned j = j0 + (unsigned)q;
+      const double vj = (double)key_value(kj[q]);
+      const bool lt = kj[q] < key, e = kj[q] == key;
+      below += lt ? 1u : 0u;
+      eq += e ? 1u : 0u;
+      if (lt) bsum += vj;
+      if (lt || (e && j <= (unsigned)lane)) psum += vj;
+      if (lt || (e && j < (unsigned)lane)) ++rank;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (act) wk[rank] = key;                       // sorted order
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  bool cand = false;
+  if (act) {
+    const unsigned nk = rank + 1u < cc ? wk[rank + 1u] : succ_k;
+    const double v = (double)key_value(key);
+    const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
+    const long long i = (long long)rs + rank;
+    cand = i >= 1 && i <= (long long)n - 2 &&
+           position_is_candidate(v, nv, (double)(i + 1), ps + psum, (double)n, total, ternary);
+    if (cand) {
+      Best cb;
+      cb.cost = cost_of(v, rs + below, ps + bsum, eq, n, total, ternary);
+      cb.order = rs + below;
+      cb.value = key_value(key);
+      if (better(cb, best)) best = cb;
+    }
+  }
+  const unsigned long long firsts = __ballot(cand && below == rank);
+  if (lane == 0 && firsts) atomicAdd(&lds->n_cand, (unsigned)__popcll(firsts));
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return true;
 }
 
 // gather sweep: every sub-sampled key of a flagged bin goes to its slot's segment of the LDS list; keys
@@ -1438,14 +1489,33 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
         __syncthreads();
       }
       LSQ_MARK(4);
+      LSQ_WSTAT0();
+      const long long wp_t0 = (long long)clock64();
+      (void)wp_t0;
+      // phase 1: a wave per slot -- sub-bin histogram and scan; flagged sub-bins are queued (the role table's
+      // bytes hold the queue: the gather is done with it)
+      if (tid == 0) lds->n_task = 0;
+      __syncthreads();
       for (unsigned si = sb + (unsigned)wid; si < se; si += kWaves) {
+        LSQ_WSTAT(1, 1);
         const WaveOut wo = lds->slot[si].cnt <= (unsigned)kSmallSeg ? resolve_slot_wave<1>(lds, n, si, best)
                                                                     : resolve_slot_wave<4>(lds, n, si, best);
         best = wo.best;
         if (!wo.ok) {
-          if (lane == 0) lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)si;
+          if (lane == 0 && atomicOr(&lds->slot[si].pad, 1u) == 0u) lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)si;
         }
       }
+      __syncthreads();
+      // phase 2: the queued sub-bins, round-robin over all 16 waves
+      const unsigned n_task = min(lds->n_task, (unsigned)kTaskCap);
+      for (unsigned t = (unsigned)wid; t < n_task; t += kWaves) {
+        const SubTask tk = lds->task[t];
+        if (!resolve_task_wave(lds, n, tk, best)) {
+          if (lane == 0 && atomicOr(&lds->slot[tk.slot].pad, 1u) == 0u)
+            lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)tk.slot;
+        }
+      }
+      LSQ_WSTAT(0, (long long)clock64() - wp_t0);
       __syncthreads();
       LSQ_MARK(5);
       const unsigned n_slow = lds->n_slow;
@@ -1729,5 +1799,8 @@ extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip,
 #ifdef LSQ_PHASE_CLOCKS
 extern "C" int lsq_debug_read_clocks(long long* host32) {
   return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(lsq::g_phase_clocks), 32 * sizeof(long long));
+}
+extern "C" int lsq_debug_read_wave_stats(long long* host64) {
+  return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(lsq::g_wave_stats), 64 * sizeof(long long));
 }
 #endif

@@ -23,3 +23,7 @@ for c, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     print(f'C={c} H={h}: ' + ', '.join(f'{names[i]}={buf[i] - t0}' for i in names if buf[i]))
     print(f'      hist sweep: sweep + reductions {buf[8] - buf[15]}, level-1 scan {buf[14] - buf[8]}, slot records {buf[16] - buf[14]}')
     print(f'      wave 0, last slot: hist {buf[21] - buf[20]}, sub-bin scan {buf[22] - buf[21]}, flagged sub-bins {buf[23] - buf[22]}  (segment {buf[25]} keys, {buf[26]} flagged sub-bins)')
+    ws = (ctypes.c_longlong * 64)()
+    lib.lsq_debug_read_wave_stats(ws)
+    print('      wave path per wave (cycles/slots/flagged sub-bins/ranked keys): ' +
+          ' '.join(f'{ws[4 * w]}/{ws[4 * w + 1]}/{ws[4 * w + 2]}/{ws[4 * w + 3]}' for w in range(16)))
