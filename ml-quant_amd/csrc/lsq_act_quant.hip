@@ -100,9 +100,11 @@ struct Slot1 {
 // one flagged sub-bin of a slot, queued by the wave that scanned the slot and resolved by whichever wave is
 // free: the 16 waves then share the expensive part instead of one wave walking all sub-bins of its slot
 struct SubTask {
-  unsigned short slot, sub;      // slot index, sub-bin index inside the level-1 bin
-  unsigned short bits, pad;      // sub-bin index width (6 or 8)
-  unsigned cc, rs, ns;           // keys in the sub-bin, sorted position in front of it, next non-empty sub-bin
+  unsigned short slot, bits;     // slot index; width of the sub-bin index (6 or 8, +6 per refinement, <= 18)
+  unsigned sub;                  // sub-bin index inside the level-1 bin (`bits` wide)
+  unsigned cc, rs, ns;           // keys in the sub-bin, sorted position in front of it, next non-empty sub-bin at this
+                                 // level (kNoKey: none -- the successor key is succ_key, or the slot's when that is kNoKey too)
+  unsigned succ_key;
   double ps;                     // prefix sum in front of it
 };
 constexpr int kTaskCap = (L1_BINS * 2) / (int)sizeof(SubTask);   // what the role table's bytes hold (682)
@@ -148,7 +150,8 @@ struct SolverLds {
   double ws[kWaves];
   Best wbest[kWaves];
   // scalars
-  unsigned n_sub, n_cand, n_slow, blk_succ, n_task;
+  unsigned n_sub, n_cand, n_slow, blk_succ;
+  unsigned task_cnt[3];                           // tasks queued in the current / next / after-next round
   unsigned dbg_slow, dbg_gathered, dbg_rowpass;   // diagnostics written back to the row header
   unsigned rg_lo[4], rg_len[4], rg_first[4], rg_succbin[4], rg_last[4], n_rg;   // runs of consecutive flagged bins
   unsigned minkey;
@@ -1053,13 +1056,13 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     if (fl[u]) {
-      const unsigned at = atomicAdd(&lds->n_task, 1u);
+      const unsigned at = atomicAdd(&lds->task_cnt[0], 1u);
       if (at < (unsigned)kTaskCap) {
         SubTask tk;
         tk.slot = (unsigned short)si;
-        tk.sub = (unsigned short)(lane * PER + u);
+        tk.sub = (unsigned)(lane * PER + u);
         tk.bits = (unsigned short)kSubBits;
-        tk.pad = 0;
+        tk.succ_key = kNoKey;
         tk.cc = c[u];
         tk.rs = r0s[u];
         tk.ns = nsub[u];
@@ -1077,9 +1080,86 @@ __device__ __forceinline__ WaveOut resolve_slot_wave(SolverLds* lds, unsigned n,
   return wo;
 }
 
+// A flagged sub-bin with more than 64 keys that are not all equal (a value of high multiplicity -- the image of
+// the zeros of a ReLU under the next layer's batch norm -- next to ordinary keys): histogram its keys over
+// the next (up to) 6 key bits, scan, and queue the children that may hold a candidate.  Same arithmetic as
+// the first level: exact integer sums per child, conservative candidate test.  Returns false only when
+// the queue is full.
+__device__ __forceinline__ bool refine_task_wave(SolverLds* lds, unsigned n, const SubTask tk, unsigned succ_k,
+                                                 unsigned child_base, unsigned* child_cnt) {
+  const Args& a = lds->args;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool ternary = a.ternary != 0;
+  const double total = lds->total;
+  const Slot1 s1 = lds->slot[tk.slot];
+  const unsigned* const seg = lds->k.list + s1.base;
+  const unsigned seg_n = s1.cnt;
+  unsigned long long* const h = lds->u.whist[wid];
+  const unsigned pbits = tk.bits, pshift = (unsigned)L1_SHIFT - pbits;        // parent: low bits below its index
+  const unsigned nb = min(6u, pshift);                                          // child index bits (pshift > 0 here)
+  const unsigned cshift = pshift - nb;                                          // child: low bits below its index
+  const unsigned pref = ((unsigned)s1.bin << pbits) | tk.sub;
+  h[lane] = 0ull;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (unsigned i = lane; i < seg_n; i += kWave) {
+    const unsigned key = seg[i];
+    if ((key >> pshift) == pref)
+      atomicAdd(&h[(key >> cshift) & ((1u << nb) - 1u)], kOne | (unsigned long long)(key & ((1u << cshift) - 1u)));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const unsigned long long hv = h[lane];
+  const unsigned c = (unsigned)lane < (1u << nb) ? (unsigned)(hv >> 42) : 0u;
+  const unsigned child = (tk.sub << nb) | (unsigned)lane;                       // index at the new level
+  const unsigned hi_key = ((unsigned)s1.bin << L1_SHIFT) | (child << cshift);
+  const double sm = c ? bin_sum_exact(hi_key, c, hv & kLowMask) : 0.0;
+  const unsigned ic = wave_incl_scan(c);
+  const double is = wave_incl_scan(sm);
+  unsigned nxt = c ? (unsigned)lane : kNoKey;                                   // first non-empty child in a higher lane
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_down(nxt, d);
+    if (lane + d < 64) nxt = min(nxt, o);
+  }
+  const unsigned up1 = __shfl_down(nxt, 1);
+  const unsigned after = lane < 63 ? up1 : kNoKey;
+  bool flag = false;
+  const unsigned r0 = tk.rs + (ic - c);
+  const double p0 = tk.ps + (is - sm);
+  if (c) {
+    const double vlo = (double)key_value(hi_key);
+    const double vhi = (double)key_value(hi_key | ((1u << cshift) - 1u));
+    double next_hi = vhi;
+    if (after != kNoKey)
+      next_hi = (double)key_value(((unsigned)s1.bin << L1_SHIFT) | ((((tk.sub << nb) | after)) << cshift) | ((1u << cshift) - 1u));
+    else if (succ_k != kNoKey)
+      next_hi = (double)key_value(succ_k);
+    flag = may_hold_candidate(r0, c, p0, sm, vlo, vhi, next_hi, n, total, ternary);
+  }
+  bool ok = true;
+  if (flag) {
+    const unsigned at = child_base + atomicAdd(child_cnt, 1u);
+    if (at < (unsigned)kTaskCap) {
+      SubTask ch;
+      ch.slot = tk.slot;
+      ch.bits = (unsigned short)(pbits + nb);
+      ch.sub = child;
+      ch.cc = c;
+      ch.rs = r0;
+      ch.ns = after != kNoKey ? ((tk.sub << nb) | after) : kNoKey;
+      ch.succ_key = succ_k;
+      ch.ps = p0;
+      lds->task[at] = ch;
+    } else {
+      ok = false;
+    }
+  }
+  return __ballot(!ok) == 0ull;
+}
+
 // phase 2 of the wave path: one flagged sub-bin.  Returns false when the sub-bin holds more than 64
 // distinct keys (the slot then goes to the block path).
-__device__ __forceinline__ bool resolve_task_wave(SolverLds* lds, unsigned n, const SubTask tk, Best& best) {
+__device__ __forceinline__ bool resolve_task_wave(SolverLds* lds, unsigned n, const SubTask tk, Best& best,
+                                                  unsigned child_base, unsigned* child_cnt) {
   const Args& a = lds->args;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool ternary = a.ternary != 0;
@@ -1113,13 +1193,13 @@ __device__ __forceinline__ bool resolve_task_wave(SolverLds* lds, unsigned n, co
     pos += (unsigned)__popcll(mm);
     if (i < seg_n && pk == npref) succ_l = min(succ_l, key);
   }
-  const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : succ_b;
+  const unsigned succ_k = ns != kNoKey ? wave_min(succ_l) : (tk.succ_key != kNoKey ? tk.succ_key : succ_b);
   const double succ_v = succ_k != kNoKey ? (double)key_value(succ_k) : INFINITY;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (cc > (unsigned)kWave) {
     kmin = wave_min(kmin);
     kmax = ~wave_min(~kmax);
-    if (kmin != kmax) return false;              // many distinct keys in one sub-bin: block path
+    if (kmin != kmax) return refine_task_wave(lds, n, tk, succ_k, child_base, child_cnt);   // dense and mixed: 6 bits deeper
     // a run of cc equal keys (saturated clamp value, exact zeros, constant rows)
     const double v = (double)key_value(kmin);
     if (run_has_candidate(v, cc, rs, ps, succ_v, n, total, ternary)) {
@@ -1494,7 +1574,7 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
       (void)wp_t0;
       // phase 1: a wave per slot -- sub-bin histogram and scan; flagged sub-bins are queued (the role table's
       // bytes hold the queue: the gather is done with it)
-      if (tid == 0) lds->n_task = 0;
+      if (tid < 3) lds->task_cnt[tid] = 0u;
       __syncthreads();
       for (unsigned si = sb + (unsigned)wid; si < se; si += kWaves) {
         LSQ_WSTAT(1, 1);
@@ -1506,17 +1586,29 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
         }
       }
       __syncthreads();
-      // phase 2: the queued sub-bins, round-robin over all 16 waves
-      const unsigned n_task = min(lds->n_task, (unsigned)kTaskCap);
-      for (unsigned t = (unsigned)wid; t < n_task; t += kWaves) {
-        const SubTask tk = lds->task[t];
-        if (!resolve_task_wave(lds, n, tk, best)) {
-          if (lane == 0 && atomicOr(&lds->slot[tk.slot].pad, 1u) == 0u)
-            lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)tk.slot;
+      // phase 2: the queued sub-bins, round-robin over all 16 waves.  A dense mixed sub-bin queues children (6
+      // key bits deeper) behind the current round; they form the next round.  Three rotating counters make one
+      // barrier per round enough: round r appends through counter (r+1)%3, which everyone reads after the
+      // barrier, while thread 0 clears counter (r+2)%3 (last read a full round ago, next used a full round on).
+      {
+        unsigned t_begin = 0, t_end = min(lds->task_cnt[0], (unsigned)kTaskCap);
+        if (t_end == 0u) __syncthreads();            // (no round, no barrier: the slow list must still be visible)
+        for (unsigned r = 0; t_begin < t_end; ++r) {
+          unsigned* const child_cnt = &lds->task_cnt[(r + 1u) % 3u];
+          if (tid == 0) lds->task_cnt[(r + 2u) % 3u] = 0u;
+          for (unsigned t = t_begin + (unsigned)wid; t < t_end; t += kWaves) {
+            const SubTask tk = lds->task[t];
+            if (!resolve_task_wave(lds, n, tk, best, t_end, child_cnt)) {
+              if (lane == 0 && atomicOr(&lds->slot[tk.slot].pad, 1u) == 0u)
+                lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)tk.slot;
+            }
+          }
+          __syncthreads();
+          t_begin = t_end;
+          t_end = min(t_end + *child_cnt, (unsigned)kTaskCap);
         }
       }
       LSQ_WSTAT(0, (long long)clock64() - wp_t0);
-      __syncthreads();
       LSQ_MARK(5);
       const unsigned n_slow = lds->n_slow;
       if (tid == 0) lds->dbg_slow += n_slow;

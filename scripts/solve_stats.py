@@ -15,18 +15,21 @@ model = bench.build_model(bench.imagenet_arch(), dev)
 x = torch.randn(64, 3, 224, 224, device=dev)
 WS_ROW = _hip.lib().lsq_solver_workspace_bytes(1)
 
-def hook(mod, args, out):
+_orig = _hip.act_quant
+
+
+def act_quant(x_in, geom, *rest, **kw):
+    _orig(x_in, geom, *rest, **kw)
     torch.cuda.synchronize()
     ws = _hip.solver_workspace(64, dev)[:64 * WS_ROW].cpu().numpy().reshape(64, WS_ROW)
     hdr = ws[:, :32].copy().view(np.uint32).reshape(64, 8)
     gathered = ws[:, 24:32].copy().view(np.float64).reshape(64)
     tflag, n, pad = hdr[:, 0], hdr[:, 2], hdr[:, 3]
-    print(f'{tuple(args[0].shape)}  n={n[0]}  flagged bins mean {tflag.mean():.1f} max {tflag.max()}  '
+    print(f'{tuple(x_in.shape)}  n={n[0]}  flagged bins mean {tflag.mean():.1f} max {tflag.max()}  '
           f'gathered mean {gathered.mean():.0f} max {gathered.max():.0f}  slow slots mean {(pad & 0xFFFF).mean():.2f} '
           f'max {(pad & 0xFFFF).max()}  row-pass slots max {(pad >> 16).max()}')
 
-for m in model.modules():
-    if isinstance(m, QuantConv2d):
-        m.register_forward_hook(hook)
+
+_hip.act_quant = act_quant          # (the fused blocks call the binding directly: no module hooks to hang on)
 with torch.no_grad():
     model(x)

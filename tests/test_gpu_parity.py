@@ -182,10 +182,14 @@ def test_solver_hard_rows():
         'equal_big': np.full((2, 60000), 1.75, dtype=np.float32),
         'two_values': np.where(rs.random_sample((3, 50000)) < 0.5, 0.25, 1.0).astype(np.float32),
         'narrow': (1.0 + 1e-4 * rs.standard_normal((2, 40000))).astype(np.float32),
+        # the zeros of a ReLU under the next layer's batch norm: 64 constants of multiplicity ~800 each, inside
+        # sub-bins that also hold ordinary keys (dense MIXED sub-bins -> refinement through the task queue)
+        'relu_affine': (np.maximum(rs.standard_normal((3, 64, 1600)), 0) * (0.5 + rs.random_sample((1, 64, 1))) * 1.7
+                        + rs.standard_normal((1, 64, 1)) * 0.5 - 0.7).reshape(3, -1).astype(np.float32).clip(-3, 3),
     }
     for tag, rows in cases.items():
         for ternary in (False, True):
-            skip = 3 if tag == 'gauss' else 1
+            skip = 3 if tag in ('gauss', 'relu_affine') else 1
             v12, _ = hip.solve_rows(torch.from_numpy(rows).to(DEV), skip, ternary)
             exact = E.solve_rows(rows, ternary, skip)
             assert np.array_equal(v12[0].cpu().numpy(), exact), (tag, ternary, v12[0].cpu().numpy(), exact)
@@ -230,6 +234,12 @@ def test_solver_rare_paths_are_exercised():
     # a narrow band of 30000 distinct values inside one sub-bin range -> dense sub-bins (> 64 keys)
     dense = (1.0 + np.arange(30000, dtype=np.float64) * 2.0 ** -22).astype(np.float32)[None, :].repeat(2, 0)
     dense[1] = dense[1][::-1]
+    # (the same structure with a duplicate-heavy value inside is resolved by the wave-level task queue instead)
+    mixed = (np.maximum(rs.standard_normal((2, 64, 1600)), 0) * (0.5 + rs.random_sample((1, 64, 1))) * 1.7
+             + rs.standard_normal((1, 64, 1)) * 0.5 - 0.7).reshape(2, -1).astype(np.float32).clip(-3, 3)
+    v, tflag, slow, rowpass = _solver_diag(mixed, 1, False)
+    assert (slow + rowpass).max() == 0, (slow, rowpass)
+    assert np.array_equal(v, E.solve_rows(mixed, False, 1))
     v, tflag, slow, rowpass = _solver_diag(dense, 1, False)
     assert (slow + rowpass).max() >= 1, (slow, rowpass)
     assert np.array_equal(v, E.solve_rows(dense, False, 1))
