@@ -27,6 +27,7 @@
 namespace lsq {
 #ifdef LSQ_PHASE_CLOCKS
 __device__ long long g_phase_clocks[32];
+__device__ long long g_block_times[1024][2];    // solve kernel: constant-rate clock at entry / exit of each workgroup
 __device__ long long g_wave_stats[16][4];       // block 0: cycles in the wave path, slots, flagged sub-bins, ranked keys
 #define LSQ_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)clock64(); } while (0)
 #define LSQ_NOTE(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)(v); } while (0)
@@ -1743,6 +1744,9 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
   const float* xrow = a.x + (long long)row * a.row_elems;
   const unsigned char* wrow = a.ws + (long long)row * kWsRow;
   LSQ_MARK(10);
+#ifdef LSQ_PHASE_CLOCKS
+  if (tid == 0 && row < 1024) g_block_times[row][0] = (long long)wall_clock64();
+#endif
   const RowHeader h = *reinterpret_cast<const RowHeader*>(wrow);
   if (tid == 0) {
     lds->args = a;
@@ -1771,6 +1775,9 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
     RowHeader* hw = reinterpret_cast<RowHeader*>(a.ws + (long long)row * kWsRow);
     hw->pad = lds->dbg_slow | (lds->dbg_rowpass << 16);
     hw->pad2 = (double)lds->dbg_gathered;
+#ifdef LSQ_PHASE_CLOCKS
+    if (row < 1024) g_block_times[row][1] = (long long)wall_clock64();
+#endif
   }
 }
 
@@ -1891,6 +1898,9 @@ extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip,
 #ifdef LSQ_PHASE_CLOCKS
 extern "C" int lsq_debug_read_clocks(long long* host32) {
   return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(lsq::g_phase_clocks), 32 * sizeof(long long));
+}
+extern "C" int lsq_debug_read_block_times(long long* host2048) {
+  return (int)hipMemcpyFromSymbol(host2048, HIP_SYMBOL(lsq::g_block_times), 2048 * sizeof(long long));
 }
 extern "C" int lsq_debug_read_wave_stats(long long* host64) {
   return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(lsq::g_wave_stats), 64 * sizeof(long long));

@@ -27,3 +27,11 @@ for c, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     lib.lsq_debug_read_wave_stats(ws)
     print('      wave path per wave (cycles/slots/flagged sub-bins/ranked keys): ' +
           ' '.join(f'{ws[4 * w]}/{ws[4 * w + 1]}/{ws[4 * w + 2]}/{ws[4 * w + 3]}' for w in range(16)))
+    bt = (ctypes.c_longlong * 2048)()
+    lib.lsq_debug_read_block_times(bt)
+    import numpy as np
+    t = np.array(bt[:2 * n]).reshape(n, 2).astype(np.float64)
+    start, dur = (t[:, 0] - t[:, 0].min()) / 100.0, (t[:, 1] - t[:, 0]) / 100.0      # 100 MHz -> us
+    end = (t[:, 1] - t[:, 0].min()) / 100.0
+    print(f'      solve per row (us): start spread {start.max():.1f}; duration min {dur.min():.1f} median {np.median(dur):.1f} '
+          f'p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f}; last row ends at {end.max():.1f}')
