@@ -28,6 +28,7 @@ namespace lsq {
 #ifdef LSQ_PHASE_CLOCKS
 __device__ long long g_phase_clocks[32];
 __device__ long long g_block_times[1024][2];    // solve kernel: constant-rate clock at entry / exit of each workgroup
+__device__ long long g_sweep_times[2][1024][2]; // the same for the histogram sweep [0] and the last plane sweep [1]
 __device__ long long g_wave_stats[16][4];       // block 0: cycles in the wave path, slots, flagged sub-bins, ranked keys
 #define LSQ_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)clock64(); } while (0)
 #define LSQ_NOTE(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_clocks[i] = (long long)(v); } while (0)
@@ -1666,6 +1667,9 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   L* lds = reinterpret_cast<L*>(smem);
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
+#ifdef LSQ_PHASE_CLOCKS
+  if (tid == 0 && row < 1024) g_sweep_times[HIST ? 0 : 1][row][0] = (long long)wall_clock64();
+#endif
   const float* xrow = a.x + (long long)row * a.row_elems;
   if constexpr (HIST) {
     for (int i = tid; i < L1_BINS; i += kThreads) lds->hist1[i] = 0ull;
@@ -1731,6 +1735,10 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   }
   if constexpr (HIST) LSQ_MARK(16);
   LSQ_MARK(9);
+#ifdef LSQ_PHASE_CLOCKS
+  __syncthreads();
+  if (tid == 0 && row < 1024) g_sweep_times[HIST ? 0 : 1][row][1] = (long long)wall_clock64();
+#endif
 }
 
 // Kernel B: the solve.  Reads the row's slot records, gathers the flagged bins' keys with a second
@@ -1898,6 +1906,9 @@ extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip,
 #ifdef LSQ_PHASE_CLOCKS
 extern "C" int lsq_debug_read_clocks(long long* host32) {
   return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(lsq::g_phase_clocks), 32 * sizeof(long long));
+}
+extern "C" int lsq_debug_read_sweep_times(long long* host4096) {
+  return (int)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(lsq::g_sweep_times), 4096 * sizeof(long long));
 }
 extern "C" int lsq_debug_read_block_times(long long* host2048) {
   return (int)hipMemcpyFromSymbol(host2048, HIP_SYMBOL(lsq::g_block_times), 2048 * sizeof(long long));

@@ -35,3 +35,9 @@ for c, h in ((64, 56), (128, 28), (256, 14), (512, 7)):
     end = (t[:, 1] - t[:, 0].min()) / 100.0
     print(f'      solve per row (us): start spread {start.max():.1f}; duration min {dur.min():.1f} median {np.median(dur):.1f} '
           f'p90 {np.percentile(dur, 90):.1f} max {dur.max():.1f}; last row ends at {end.max():.1f}')
+    st = (ctypes.c_longlong * 4096)()
+    lib.lsq_debug_read_sweep_times(st)
+    sw = np.array(st[:]).reshape(2, 1024, 2)[:, :n, :].astype(np.float64) / 100.0
+    t0 = sw[0, :, 0].min()
+    print(f'      timeline (us from the first histogram-sweep workgroup): hist sweep {sw[0, :, 0].min() - t0:.1f}..{sw[0, :, 1].max() - t0:.1f} | '
+          f'solve {t[:, 0].min() / 100.0 - t0:.1f}..{t[:, 1].max() / 100.0 - t0:.1f} | plane-1 sweep {sw[1, :, 0].min() - t0:.1f}..{sw[1, :, 1].max() - t0:.1f}')
