@@ -10,11 +10,11 @@
 // accumulation -- inside the 1e-4 bound where single bf16 (2^-9) is not.  Zero padding and channel
 // padding are exact (x = 0 contributes 0).
 //
-// Two kernels.  signw_conv_patch (stride 1): the workgroup keeps, per 32-channel chunk, the whole input
-// patch its 128 output pixels touch in LDS (already batch-norm-folded, clamped and split), and all
-// KH*KW taps read their B fragments from it at shifted rows -- each input element is loaded and
-// converted once per workgroup instead of once per tap.  signw_conv_tiled (any stride): im2col staging
-// per (tap, chunk).
+// Two kernels.  signw_conv_patch (any stride whose input patch fits LDS -- every ResNet layer): per 16-channel
+// chunk the workgroup keeps the whole input patch its output pixels touch in LDS (already batch-norm-folded,
+// clamped and split) together with the expanded +-1 weights of all taps, and the taps read their fragments
+// at precomputed addresses -- each input element is loaded and converted once per workgroup instead of
+// once per tap.  signw_conv_tiled (fall-back): im2col staging per (tap, 32-channel chunk).
 
 #include "lsq_common.h"
 
@@ -68,8 +68,8 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 // from 4 bytes of the packed plane per out-channel and (b) the activation chunk already clamped /
 // batch-norm-folded and split into bf16 hi and lo, both as [row][32 k] with a 16-byte row pad so that
 // the 16-byte MFMA fragment reads of a 32-lane group hit distinct banks.  Global loads of chunk i+1
-// are issued before the MFMAs of chunk i and written to the other LDS buffer after them (one barrier
-// per chunk).  Each wave owns TM x TN 32x32 tiles: 2*TM*TN*2 MFMAs per chunk against
+// are issued before the MFMAs of chunk i and written to LDS after them (one buffer, two barriers per
+// chunk: half the LDS, three workgroups per CU, measured faster than two buffers and one barrier).  Each wave owns TM x TN 32x32 tiles: 2*TM*TN*2 MFMAs per chunk against
 // (TM + 2*TN)*2 fragment reads.
 constexpr int kKC = 32;                         // channels per K-chunk
 constexpr int kRowB = kKC * 2 + 16;             // LDS row pitch in bytes (64 data + 16 pad)
