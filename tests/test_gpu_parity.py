@@ -705,3 +705,48 @@ def test_stem_tail_pool_bias_relu_kernel(shape, k, stride, pad):
         hip.pool_bias_relu_nhwc(x.contiguous(), k, stride, pad, b, True)          # NCHW input
     assert hip.lib().lsq_pool_bias_relu_nhwc(None, 1, 1, 4, 4, 2, 2, 0, None, 0, y.data_ptr(), None) == -1       # LSQ_E_NULL
     assert hip.lib().lsq_pool_bias_relu_nhwc(x.data_ptr(), 1, 1, 4, 4, 2, 2, 2, None, 0, y.data_ptr(), None) != 0   # 2*pad > k
+
+
+def test_random_conv_geometries_against_oracle():
+    """Forty random geometries (kernel 1..5 per axis, stride 1..3, padding, dilation 1..2, groups, ragged channel
+    counts, several images) through both convolution kernels -- fp activations (MFMA patch / im2col kernels)
+    and ls-2 activations with injected scales (XNOR kernel) -- against the oracle."""
+    from quant.binary.binary_conv import QuantConv2d
+    rs = np.random.RandomState(20240917)
+    done = 0
+    while done < 40:
+        groups = int(rs.choice([1, 1, 1, 2, 4]))
+        cin = groups * int(rs.choice([3, 8, 16, 20, 33, 64, 80]))
+        cout = groups * int(rs.choice([4, 16, 24, 64, 72, 130]))
+        kh, kw = int(rs.randint(1, 6)), int(rs.randint(1, 6))
+        stride = (int(rs.randint(1, 4)), int(rs.randint(1, 4))) if rs.rand() < 0.5 else int(rs.randint(1, 3))
+        dil = (int(rs.randint(1, 3)), int(rs.randint(1, 3)))
+        pad = (int(rs.randint(0, 3)), int(rs.randint(0, 3)))
+        n, h, w = int(rs.randint(1, 5)), int(rs.randint(5, 40)), int(rs.randint(5, 40))
+        if h + 2 * pad[0] < dil[0] * (kh - 1) + 1 or w + 2 * pad[1] < dil[1] * (kw - 1) + 1:
+            continue
+        if cin * h * w > 200_000 or kh * kw > 16:
+            continue
+        done += 1
+        tag = f'gpu.rand.{done}'
+        x = detgen.normal(tag + '.x', (n, cin, h, w), scale=1.4)
+        wt = detgen.normal(tag + '.w', (cout, cin // groups, kh, kw), scale=0.07)
+        b = detgen.normal(tag + '.b', (cout,), scale=0.1)
+        wsc = P.weight_scales(wt, 'ls-1')
+        clamp = {'kind': 'symmetric', 'alpha': 2}
+        for xs in ('fp', 'ls-2'):
+            conv = QuantConv2d(xs, 'ls-1', cin, cout, (kh, kw), clamp, stride=stride, padding=pad, dilation=dil, groups=groups)
+            with torch.no_grad():
+                conv.weight.copy_(wt)
+                conv.bias.copy_(b)
+                conv.w_approximate.v1.copy_(wsc[0])
+            conv.eval().to(DEV)
+            details = {}
+            ref = P.quant_conv2d(x, wt, b, xs, 'ls-1', wsc, clamp, stride, pad, dil, groups, details=details)
+            if xs != 'fp':
+                conv.x_approximate._forced_scales = torch.stack([v.reshape(-1) for v in details['act_scales']]).to(DEV)   # the oracle's scales
+            with torch.no_grad():
+                y = conv(x.to(DEV)).cpu()
+            geo = (xs, (n, cin, h, w), cout, (kh, kw), stride, pad, dil, groups)
+            assert y.shape == ref.shape, geo
+            assert rel_err(y, ref) <= TOL, (geo, rel_err(y, ref))
