@@ -1,0 +1,29 @@
+// Single-launch activation quantizer (lsq_act_fused.hip), called by lsq_act_quant for the LS-2 / LS-T
+// solver schemes when the row's sub-sample fits the register file of one workgroup.
+#pragma once
+
+#include "lsq_common.h"
+
+namespace lsq {
+
+struct FusedArgs {
+  const float* x;
+  long long row_elems;      // M = C*H*W
+  int C, H, W, cg, Gg, Gt, Hp, Wp, pad_h, pad_w;
+  float alpha;
+  const float* pre_scale;   // [C] or null (folded eval batch norm)
+  const float* pre_shift;
+  unsigned long long* planes;
+  long long plane_words;    // words of one plane (all rows)
+  long long row_words;      // words of one row of one plane
+  float* scales;            // [2][N]
+  int N;
+  int ternary;
+};
+
+constexpr int kFusedNotEligible = 1;   // the shape is left to the streaming three-kernel path
+
+// LSQ_OK, an hipError_t, or kFusedNotEligible (nothing launched).  skip is the reference's 3.
+int fused_act_quant(const FusedArgs& a, hipStream_t st);
+
+}  // namespace lsq

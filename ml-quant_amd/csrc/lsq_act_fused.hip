@@ -1,0 +1,1034 @@
+// Single-launch LS-2 / LS-T activation quantizer for gfx950 (quant/binary/quantization.py:59-115 +
+// quant/binary/optimal.py:41-155 behind QuantConv2d.forward, binary_conv.py:161-164).
+//
+// One workgroup owns one row (one sample).  What the streaming path (lsq_act_quant.hip) hands
+// from kernel to kernel through HBM stays on chip here:
+//
+//   * rows of at most 1024 (channel-group, pixel) items -- the 14x14 and 7x7 layers of ResNet-18, every layer of
+//     the CIFAR network, LeNet -- are read ONCE: a lane keeps the 64 clamped channel values of its pixel in
+//     registers, packs plane 0, feeds the solver from the registers and packs plane 1 / sums |x - v1 b1| from
+//     them again (1x the algorithmic traffic, one launch);
+//   * longer rows (28x28: 33 451 sub-sampled keys, 56x56: 66 902) are read TWICE: a flat coalesced walk that
+//     keeps the row's sub-sampled keys in registers (4 keys per 3 float4 loads; <= 68 registers per lane), the
+//     solve from those registers, then one lane = 4-pixel sweep that packs both planes and the second scale.
+//     The streaming path's third read (the solve's gather) is gone.
+//
+// The solve is the same exact radix select as the streaming path (13-bit level-1 histogram whose words carry
+// count and the exact integer sum of the low key bits; conservative bin tests; exact fp64 candidate tests;
+// closed-form cost), but the refinement below level 1 works on the resident keys directly: per round every
+// flagged node (a key prefix of 13 / 19 / 25 bits) is histogrammed over its next 6 key bits by ONE pass of all
+// lanes over their registers (table walk role[] -> centry[][] from the key's prefix to its node), one wave per
+// node scans the 64 children, and flagged children become: an analytic run (prefix = whole key), a brute-force
+// task (<= 64 keys: captured into an LDS arena by the next pass and ranked with shuffles) or a node of the
+// next round.  Two passes over the registers (~1 us each) replace the gather sweep over HBM.  Anything the
+// fixed-size tables cannot take (more than 40 flagged level-1 bins, table or list overflow) goes to a block-level
+// path that histograms straight from the row in memory: slow, general, exact.
+//
+// Results are bit-identical to the streaming path and to oracle/lsq_exact.py (same candidate set, same
+// closed-form cost, same (cost, sorted position) argmin).
+
+#include "lsq_act_fused.h"
+#include "lsq_solver_math.h"
+
+namespace lsq {
+#ifdef LSQ_PHASE_CLOCKS
+__device__ long long g_fused_times[1024][8];    // constant-rate clock (100 MHz) at the phase marks of each workgroup
+#define FMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_fused_times[blockIdx.x][i] = (long long)wall_clock64(); } while (0)
+#else
+#define FMARK(i) do {} while (0)
+#endif
+namespace {
+
+constexpr int kNzCap = 2048;                   // non-empty level-1 bins tested per chunk of the level-1 scan
+constexpr int kSlotCap = 64;                   // flagged level-1 bins per scan round (slot records)
+constexpr int kFastSlots = 40;                 // flagged level-1 bins the on-chip refinement takes
+constexpr int kNodeCap = 48;                   // nodes over all rounds (round 0 = the flagged level-1 bins)
+constexpr int kTaskCap = 256;                  // brute-force tasks over all rounds
+constexpr int kCellCap = kNodeCap + kTaskCap;  // successor cells
+constexpr int kArena = 4096;                   // captured keys of the brute-force tasks
+constexpr int L2_SHIFT = 8, L2_BINS = 1024;    // block path: key bits [17:8]
+constexpr int L3_BINS = 256;                   // block path: key bits [7:0]
+constexpr int kKeysPerLane = L3_BINS / kWave;
+constexpr int kSeg3 = 8;
+constexpr unsigned kTaskBit = 0x8000u;
+
+struct Node {
+  unsigned prefix, cnt, r0, cell;   // key >> (31 - bits); keys; sorted position in front; successor cell
+  double p0;                        // prefix sum in front
+  unsigned root, pad;               // level-1 slot it descends from
+};
+struct Task {
+  double ps;
+  unsigned cc, rs, base, cell;      // keys, sorted position in front, arena offset, successor cell
+  unsigned short node, child;       // table entry to clear once resolved
+  unsigned root;
+};
+struct Seg3 {
+  unsigned pref, next_pref, cnt, r0;
+  double p0;
+};
+struct BlockHists {
+  unsigned long long hist2[L2_BINS];
+  unsigned hist3[kSeg3][L3_BINS];
+};
+
+// Everything below is parameterised by the workgroup size: the per-lane working set of the solver is the same
+// whatever the number of lanes, so FEWER lanes with MORE registers each (512 lanes x 256 VGPRs) leave room for
+// the resident keys of the longest rows (132 registers per lane at 56x56) where 1024 lanes x 128 VGPRs do not.
+template <int kThreads>
+struct Impl {
+static constexpr int kWaves = kThreads / kWave;
+static constexpr int kBinsPerThread = L1_BINS / kThreads;
+static constexpr int kEntries = kNzCap / kThreads;
+#ifndef KGROUP
+#define KGROUP 16
+#endif
+static constexpr int kGroup = KGROUP;      // compact-list entries per lane and chunk
+
+struct FixedLds {
+  Slot1 slot[kSlotCap];
+  Node node[kNodeCap];
+  Task task[kTaskCap];
+  unsigned cell[kCellCap];
+  unsigned task_fill[kTaskCap];
+  unsigned short nzlist2[L2_BINS];
+  unsigned short slow[kFastSlots];
+  Seg3 seg[kSeg3];
+  unsigned succ3[kSeg3];
+  unsigned wa[kWaves], wb[kWaves], wc[kWaves];
+  double ws[kWaves];
+  Best wbest[kWaves];
+  unsigned n_nodes, n_tasks, n_cells, arena_fill, blk_succ, n_slow, n_list, pad0;
+  unsigned long long slow_mask;
+  double total;
+  float v1;
+  FusedArgs args;
+};
+static constexpr int kRefineFixed = 2 * L1_BINS + kNodeCap * 64 * 12 + kArena * 4;   // role, succ, nhist, centry, arena
+static constexpr int kListCap = ((160 * 1024 - (int)sizeof(FixedLds) - kRefineFixed) / 4) & ~63;   // keys of the flagged bins
+
+struct FusedLds : FixedLds {
+  union {
+    struct {                                       // pass 1 and the level-1 scan(s); blk: block path
+      unsigned long long hist1[L1_BINS];
+      unsigned short nzlist[L1_BINS];
+      unsigned nz_r0[kNzCap];
+      double nz_p0[kNzCap];
+      BlockHists blk;
+    } a;
+    struct {                                       // on-chip refinement
+      unsigned short role[L1_BINS];                // level-1 bin -> low byte: node + 1; high byte: successor cell + 1 of
+                                                   // the flagged bin below it
+      unsigned long long nhist[kNodeCap][64];      // node histograms of the current round
+      unsigned centry[kNodeCap][64];               // low half: child node + 1 or kTaskBit | task; high half: cell + 1
+      unsigned arena[kArena];                      // captured keys of the brute-force tasks
+      unsigned klist[kListCap];                    // every key of the flagged bins (compacted out of the registers)
+    } b;
+  };
+};
+static_assert(sizeof(FusedLds) <= 160 * 1024, "LDS budget");
+
+// exclusive block scan of (a, b, s); returns block totals.  All 1024 threads must call.
+static __device__ __forceinline__ void block_excl_scan(unsigned& a, unsigned& b, double& s, unsigned& ta, unsigned& tb,
+                                                double& ts, FusedLds* lds) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+  const double is = wave_incl_scan(s);
+  __syncthreads();
+  if (lane == 63) {
+    lds->wa[wid] = ia;
+    lds->wb[wid] = ib;
+    lds->ws[wid] = is;
+  }
+  __syncthreads();
+  unsigned oa = 0, ob = 0;
+  double os = 0.0;
+  ta = tb = 0;
+  ts = 0.0;
+  for (int w = 0; w < kWaves; ++w) {
+    if (w == wid) {
+      oa = ta;
+      ob = tb;
+      os = ts;
+    }
+    ta += lds->wa[w];
+    tb += lds->wb[w];
+    ts += lds->ws[w];
+  }
+  a = oa + ia - a;
+  b = ob + ib - b;
+  s = os + (is - s);
+}
+
+static __device__ __forceinline__ double block_sum(double v, FusedLds* lds) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds->ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < kWaves; ++w) t += lds->ws[w];
+  return t;
+}
+
+static __device__ __forceinline__ void store_lo16(unsigned* w, unsigned v) { reinterpret_cast<unsigned short*>(w)[0] = (unsigned short)v; }
+static __device__ __forceinline__ void store_hi16(unsigned* w, unsigned v) { reinterpret_cast<unsigned short*>(w)[1] = (unsigned short)v; }
+
+// ---------------------------------------------------------------------------------------------
+// Level 1: scan the 8192-bin histogram, flag the bins that may hold a candidate (optimal.py:78-80) and write
+// slot records for the flagged bins with ordinal in [round0, round0 + kSlotCap).  Same arithmetic as the
+// streaming path's scan: exact integer bin sums, fixed-order fp64 prefix scan, conservative test.  The test
+// runs over the COMPACT list of non-empty bins (they sit in a few binades, i.e. in the bin ranges of a few
+// dozen lanes), kNzCap entries at a time; loops are rolled and per-entry state is re-read from LDS instead of
+// being carried in registers: the resident keys of the caller stay live across this function.
+static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, unsigned round0, bool ternary) {
+  const unsigned long long* const hist1 = lds->a.hist1;
+  unsigned short* const nzl = lds->a.nzlist;
+  const int tid = threadIdx.x;
+  unsigned my_nz = 0, my_cnt = 0;
+  double my_sum = 0.0;
+#pragma unroll
+  for (int u = 0; u < kBinsPerThread; ++u) {
+    const unsigned b = (unsigned)kBinsPerThread * tid + u;
+    const unsigned long long h = hist1[b];
+    const unsigned c = (unsigned)(h >> 42);
+    my_nz += c ? 1u : 0u;
+    my_cnt += c;
+    my_sum += c ? bin_sum_exact(b << L1_SHIFT, c, h & kLowMask) : 0.0;
+  }
+  unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
+  double esum = my_sum, total;
+  block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
+  if (tid == 0) lds->total = total;
+  unsigned flag_base = 0;                       // flagged bins in front of the current chunk
+  for (unsigned chunk = 0; chunk < tnz; chunk += kNzCap) {
+    if (chunk) __syncthreads();                 // the previous chunk's prefixes are done with
+    if (my_nz) {                                // (most lanes own empty bins only)
+      unsigned z = enz, c = ecnt;
+      double sacc = esum;
+#pragma unroll 4
+      for (int u = 0; u < kBinsPerThread; ++u) {
+        const unsigned b = (unsigned)kBinsPerThread * tid + u;
+        const unsigned long long h = hist1[b];
+        const unsigned cn = (unsigned)(h >> 42);
+        if (cn) {
+          if (chunk == 0u) nzl[z] = (unsigned short)b;
+          if (z - chunk < (unsigned)kNzCap) {   // (unsigned wrap: entries in front of the chunk fail too)
+            lds->a.nz_r0[z - chunk] = c;
+            lds->a.nz_p0[z - chunk] = sacc;
+          }
+          ++z;
+          c += cn;
+          sacc += bin_sum_exact(b << L1_SHIFT, cn, h & kLowMask);
+        }
+      }
+    }
+    __syncthreads();
+    // entry zl = e * kThreads + tid: with the usual few hundred non-empty bins every lane tests at most one
+    for (int e = 0; e < kEntries && chunk + (unsigned)e * kThreads < tnz; ++e) {
+      const unsigned zl = (unsigned)e * kThreads + (unsigned)tid, z = chunk + zl;
+      bool fl = false;
+      unsigned b = 0, cn = 0;
+      double sm = 0.0;
+      if (z < tnz) {
+        b = nzl[z];
+        const unsigned long long h = hist1[b];
+        cn = (unsigned)(h >> 42);
+        sm = bin_sum_exact(b << L1_SHIFT, cn, h & kLowMask);
+        const double vlo = (double)key_value(b << L1_SHIFT);
+        const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        double next_hi = vhi;
+        if (z + 1 < tnz) next_hi = (double)key_value(((unsigned)nzl[z + 1] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        fl = n >= 3u && may_hold_candidate(lds->a.nz_r0[zl], cn, lds->a.nz_p0[zl], sm, vlo, vhi, next_hi, n, total, ternary);
+      }
+      unsigned eflag = fl ? 1u : 0u, dummy = 0, cflag, tdummy;
+      double dzero = 0.0, tdz;
+      block_excl_scan(eflag, dummy, dzero, cflag, tdummy, tdz, lds);
+      const unsigned ord = flag_base + eflag;
+      if (fl && ord >= round0 && ord < round0 + (unsigned)kSlotCap) {
+        Slot1 sl;
+        sl.bin = (unsigned short)b;
+        sl.next_bin = z + 1 < tnz ? nzl[z + 1] : (unsigned short)0xFFFFu;
+        sl.cnt = cn;
+        sl.r0 = lds->a.nz_r0[zl];
+        sl.succ = kNoKey;
+        sl.base = 0;
+        sl.pad = 0;
+        sl.p0 = lds->a.nz_p0[zl];
+        sl.sum = sm;
+        lds->slot[ord - round0] = sl;
+      }
+      flag_base += cflag;
+    }
+  }
+  __syncthreads();
+  return flag_base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block path: the sub-sampled keys of the row straight from memory (L2 / Infinity Cache).
+template <class F>
+static __device__ __forceinline__ void for_each_row_key(const FusedArgs& a, const float* __restrict__ xrow, unsigned n, F f) {
+  constexpr int U = 8;
+  for (unsigned j0 = threadIdx.x; j0 < n; j0 += kThreads * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = min(j0 + (unsigned)u * kThreads, n - 1u);
+      v[u] = xrow[(long long)j * 3];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j0 + (unsigned)u * kThreads < n) {
+        float xv = v[u];
+        if (a.pre_scale) {
+          const long long flat = (long long)(j0 + (unsigned)u * kThreads) * 3;
+          const int c = (int)(flat / ((long long)a.H * a.W));
+          xv = fmaf(xv, a.pre_scale[c], a.pre_shift[c]);
+        }
+        f(abs_key(clamp_sym(xv, a.alpha)));
+      }
+  }
+}
+
+// One flagged level-1 bin resolved with block-wide histograms of key bits [17:8] and [7:0] read from the
+// row in memory.  Fully general (any count, any ties); ~15 workgroup barriers per bin.
+static __device__ __forceinline__ Best resolve_slot_block(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned si,
+                                                   bool ternary, Best best) {
+  const FusedArgs& a = lds->args;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const double total = lds->total;
+  const Slot1 s1 = lds->slot[si];
+  const unsigned s1_bin = s1.bin;
+  const unsigned s1_next = s1.next_bin == 0xFFFFu ? kNoKey : (unsigned)s1.next_bin;
+  __syncthreads();
+  for (int i = tid; i < L2_BINS; i += kThreads) lds->a.blk.hist2[i] = 0ull;
+  if (tid == 0) lds->blk_succ = kNoKey;
+  __syncthreads();
+  for_each_row_key(a, xrow, n, [&](unsigned key) {
+    const unsigned b = key >> L1_SHIFT;
+    if (b == s1_bin)
+      atomicAdd(&lds->a.blk.hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
+                kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
+    else if (b == s1_next && key < lds->blk_succ)
+      atomicMin(&lds->blk_succ, key);
+  });
+  __syncthreads();
+  const unsigned succ_b = lds->blk_succ;
+  const unsigned long long h2 = lds->a.blk.hist2[tid];
+  const unsigned c2 = (unsigned)(h2 >> 42);
+  const unsigned hi_key2 = (s1_bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
+  const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
+  unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
+  double es2 = s2, ts2;
+  block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
+  if (c2) lds->nzlist2[enz2] = (unsigned short)tid;
+  __syncthreads();
+  const unsigned r02 = s1.r0 + ec2;
+  const double p02 = s1.p0 + es2;
+  unsigned next_sub = kNoKey;
+  bool f2 = false;
+  if (c2) {
+    const double vlo = (double)key_value(hi_key2);
+    const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
+    double next_hi = vhi;
+    if (enz2 + 1 < tnz2) {
+      next_sub = lds->nzlist2[enz2 + 1];
+      next_hi = (double)key_value((s1_bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
+    } else if (succ_b != kNoKey) {
+      next_hi = (double)key_value(succ_b);
+    }
+    f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, total, ternary);
+  }
+  unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
+  double dz2 = 0.0, tdz2;
+  block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
+  for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
+    const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
+    __syncthreads();
+    if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
+      Seg3 g;
+      g.pref = (s1_bin << 10) | (unsigned)tid;
+      g.next_pref = next_sub != kNoKey ? ((s1_bin << 10) | next_sub) : kNoKey;
+      g.cnt = c2;
+      g.r0 = r02;
+      g.p0 = p02;
+      lds->seg[ef2 - b3] = g;
+      lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
+    }
+    for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->a.blk.hist3[0][0])[i] = 0u;
+    __syncthreads();
+    for_each_row_key(a, xrow, n, [&](unsigned key) {
+      const unsigned p = key >> L2_SHIFT;
+      for (unsigned j = 0; j < nseg; ++j) {
+        if (p == lds->seg[j].pref)
+          atomicAdd(&lds->a.blk.hist3[j][key & (L3_BINS - 1)], 1u);
+        else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
+          atomicMin(&lds->succ3[j], key);
+      }
+    });
+    __syncthreads();
+    if ((unsigned)wid < nseg) {
+      const Seg3 g = lds->seg[wid];
+      const unsigned succ_s = lds->succ3[wid];
+      unsigned kc[kKeysPerLane];
+      unsigned lane_cnt = 0;
+      double lane_sum = 0.0;
+      unsigned first_key = kNoKey;
+#pragma unroll
+      for (int u = kKeysPerLane - 1; u >= 0; --u) {
+        kc[u] = lds->a.blk.hist3[wid][lane * kKeysPerLane + u];
+        if (kc[u]) first_key = (g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u);
+      }
+#pragma unroll
+      for (int u = 0; u < kKeysPerLane; ++u) {
+        lane_cnt += kc[u];
+        lane_sum += (double)kc[u] * (double)key_value((g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u));
+      }
+      const unsigned ic = wave_incl_scan(lane_cnt);
+      const double is = wave_incl_scan(lane_sum);
+      unsigned after = kNoKey;
+      {
+        unsigned sfx = first_key;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const unsigned o = __shfl_down(sfx, d);
+          if (lane + d < 64) sfx = min(sfx, o);
+        }
+        const unsigned up1 = __shfl_down(sfx, 1);
+        after = lane < 63 ? up1 : kNoKey;
+      }
+      unsigned run_r0 = g.r0 + (ic - lane_cnt);
+      double run_p0 = g.p0 + (is - lane_sum);
+      unsigned nextk[kKeysPerLane];
+      unsigned cur = after != kNoKey ? after : succ_s;
+#pragma unroll
+      for (int u = kKeysPerLane - 1; u >= 0; --u) {
+        nextk[u] = cur;
+        if (kc[u]) cur = (g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u);
+      }
+#pragma unroll
+      for (int u = 0; u < kKeysPerLane; ++u) {
+        if (kc[u]) {
+          const unsigned key = (g.pref << L2_SHIFT) | (unsigned)(lane * kKeysPerLane + u);
+          const double v = (double)key_value(key);
+          const double succ_v = nextk[u] != kNoKey ? (double)key_value(nextk[u]) : INFINITY;
+          if (run_has_candidate(v, kc[u], run_r0, run_p0, succ_v, n, total, ternary)) {
+            Best c;
+            c.cost = cost_of(v, run_r0, run_p0, kc[u], n, total, ternary);
+            c.order = run_r0;
+            c.value = key_value(key);
+            if (better(c, best)) best = c;
+          }
+          run_r0 += kc[u];
+          run_p0 += (double)kc[u] * v;
+        }
+      }
+    }
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-chip refinement, wave-level pieces.
+static __device__ __forceinline__ void mark_slow(FusedLds* lds, unsigned root) {
+  const unsigned long long bit = 1ull << root;
+  if ((atomicOr(&lds->slow_mask, bit) & bit) == 0ull) lds->slow[atomicAdd(&lds->n_slow, 1u)] = (unsigned short)root;
+}
+
+// One wave scans the 64 children of node k (a key prefix of 13 + 6*depth bits): exact counts and sums, the
+// conservative test, and for every child that passes it: analytic run / brute-force task / node of the next round.
+static __device__ __forceinline__ void scan_node(FusedLds* lds, unsigned n, unsigned k, unsigned cur_lo, int depth, bool ternary,
+                                          Best& best) {
+  const int lane = threadIdx.x & 63;
+  const double total = lds->total;
+  const Node nd = lds->node[k];
+  const int sh = 12 - 6 * depth;                       // key bits below the child index
+  const unsigned long long hv = lds->b.nhist[k - cur_lo][lane];
+  const unsigned c = (unsigned)(hv >> 42);
+  const unsigned base_key = nd.prefix << (sh + 6);
+  const unsigned hi_key = base_key | ((unsigned)lane << sh);
+  const double sm = c ? bin_sum_exact(hi_key, c, hv & kLowMask) : 0.0;
+  const unsigned ic = wave_incl_scan(c);
+  const double is = wave_incl_scan(sm);
+  unsigned after;                                      // first non-empty child above this one
+  {
+    unsigned sfx = c ? (unsigned)lane : kNoKey;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_down(sfx, d);
+      if (lane + d < 64) sfx = min(sfx, o);
+    }
+    const unsigned up1 = __shfl_down(sfx, 1);
+    after = lane < 63 ? up1 : kNoKey;
+  }
+  const unsigned r0 = nd.r0 + (ic - c);
+  const double p0 = nd.p0 + (is - sm);
+  const unsigned nsucc = lds->cell[nd.cell];           // smallest key above the node (exact after this round's pass)
+  const unsigned lowmask = (1u << sh) - 1u;
+  bool flag = false;
+  if (c) {
+    const double vlo = (double)key_value(hi_key);
+    const double vhi = (double)key_value(hi_key | lowmask);
+    double next_hi = vhi;
+    if (after != kNoKey)
+      next_hi = (double)key_value(base_key | (after << sh) | lowmask);
+    else if (nsucc != kNoKey)
+      next_hi = (double)key_value(nsucc);
+    flag = may_hold_candidate(r0, c, p0, sm, vlo, vhi, next_hi, n, total, ternary);
+  }
+  if (!flag) return;
+  if (sh == 0) {
+    // the child is one key value of multiplicity c
+    const double v = (double)key_value(hi_key);
+    const unsigned sk = after != kNoKey ? (base_key | after) : nsucc;
+    const double succ_v = sk != kNoKey ? (double)key_value(sk) : INFINITY;
+    if (run_has_candidate(v, c, r0, p0, succ_v, n, total, ternary)) {
+      Best cb;
+      cb.cost = cost_of(v, r0, p0, c, n, total, ternary);
+      cb.order = r0;
+      cb.value = key_value(hi_key);
+      if (better(cb, best)) best = cb;
+    }
+    return;
+  }
+  // (a record whose table slot exists but whose resources ran out is written dead -- no keys, no table entry --
+  // because the round bookkeeping counts it; its level-1 bin goes to the block path)
+  const unsigned cid = atomicAdd(&lds->n_cells, 1u);
+  bool ok = cid < (unsigned)kCellCap;
+  if (c <= (unsigned)kWave) {
+    const unsigned t = atomicAdd(&lds->n_tasks, 1u);
+    const unsigned ab = atomicAdd(&lds->arena_fill, c);
+    ok = ok && t < (unsigned)kTaskCap && ab + c <= (unsigned)kArena;
+    if (t < (unsigned)kTaskCap) {
+      Task tk;
+      tk.ps = p0;
+      tk.cc = ok ? c : 0u;
+      tk.rs = r0;
+      tk.base = ok ? ab : 0u;
+      tk.cell = ok ? cid : 0u;
+      tk.node = (unsigned short)k;
+      tk.child = (unsigned short)lane;
+      tk.root = nd.root;
+      lds->task[t] = tk;
+      if (ok) store_lo16(&lds->b.centry[k][lane], kTaskBit | t);
+    }
+  } else {
+    const unsigned q = atomicAdd(&lds->n_nodes, 1u);
+    ok = ok && q < (unsigned)kNodeCap;
+    if (q < (unsigned)kNodeCap) {
+      Node ch;
+      ch.prefix = (nd.prefix << 6) | (unsigned)lane;
+      ch.cnt = c;
+      ch.r0 = r0;
+      ch.cell = ok ? cid : 0u;
+      ch.p0 = p0;
+      ch.root = nd.root;
+      ch.pad = 0;
+      lds->node[q] = ch;
+      if (ok) store_lo16(&lds->b.centry[k][lane], q + 1u);
+    }
+  }
+  if (ok) {
+    lds->cell[cid] = after != kNoKey ? kNoKey : nsucc;
+    if (after != kNoKey) store_hi16(&lds->b.centry[k][after], cid + 1u);
+  } else {
+    mark_slow(lds, nd.root);
+  }
+}
+
+// One wave resolves a brute-force task: its <= 64 captured keys are ranked with shuffles, every position is
+// tested exactly (optimal.py:78-80) and costed in closed form.
+static __device__ __forceinline__ void resolve_task(FusedLds* lds, unsigned n, unsigned t, bool ternary, Best& best) {
+  const int lane = threadIdx.x & 63;
+  const double total = lds->total;
+  const Task tk = lds->task[t];
+  const unsigned cc = tk.cc, rs = tk.rs;
+  const double ps = tk.ps;
+  unsigned* const wk = lds->b.arena + tk.base;
+  const unsigned succ_k = lds->cell[tk.cell];
+  const bool act = (unsigned)lane < cc;
+  const unsigned key = act ? wk[lane] : kNoKey;
+  unsigned rank = 0, below = 0, eq = 0;
+  double bsum = 0.0, psum = 0.0;
+  // every lane reads the task's keys from the arena (uniform addresses: LDS broadcast, independent loads)
+  // instead of passing them around with shuffles.  Slots >= cc of the padded last group compare as kNoKey.
+  for (unsigned j0 = 0; j0 < cc; j0 += 4u) {
+    unsigned kj[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kj[q] = j0 + (unsigned)q < cc ? wk[j0 + (unsigned)q] : kNoKey;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned j = j0 + (unsigned)q;
+      const double vj = (double)key_value(kj[q]);
+      const bool lt = kj[q] < key, e = kj[q] == key;
+      below += lt ? 1u : 0u;
+      eq += e ? 1u : 0u;
+      if (lt) bsum += vj;
+      if (lt || (e && j <= (unsigned)lane)) psum += vj;
+      if (lt || (e && j < (unsigned)lane)) ++rank;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (act) wk[rank] = key;                       // sorted order
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (act) {
+    const unsigned nk = rank + 1u < cc ? wk[rank + 1u] : succ_k;
+    const double v = (double)key_value(key);
+    const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
+    const long long i = (long long)rs + rank;
+    const bool cand = i >= 1 && i <= (long long)n - 2 &&
+                      position_is_candidate(v, nv, (double)(i + 1), ps + psum, (double)n, total, ternary);
+    if (cand) {
+      Best cb;
+      cb.cost = cost_of(v, rs + below, ps + bsum, eq, n, total, ternary);
+      cb.order = rs + below;
+      cb.value = key_value(key);
+      if (better(cb, best)) best = cb;
+    }
+  }
+  if (lane == 0) store_lo16(&lds->b.centry[tk.node][tk.child], 0u);   // captured once
+}
+
+// What a key of the list does in the pass of round `round` >= 1 once its depth-0 table entry `ce` (of node k0) is
+// known to be non-zero: successor minimum, capture into a task, or further down to the histogram of a node.
+static __device__ __forceinline__ void walk_key(FusedLds* lds, unsigned key, unsigned ce, int round, unsigned cur_lo) {
+  for (int d = 0;; ++d) {
+    if (d + 1 == round && (ce >> 16)) atomicMin(&lds->cell[(ce >> 16) - 1u], key);
+    const unsigned a = ce & 0xFFFFu;
+    if (a == 0u) return;
+    if (a & kTaskBit) {
+      const unsigned t = a & 0x7FFFu;
+      const unsigned pos = atomicAdd(&lds->task_fill[t], 1u);
+      if (pos < (unsigned)kWave) lds->b.arena[lds->task[t].base + pos] = key;
+      return;
+    }
+    const unsigned k = a - 1u;                    // a node of depth d + 1
+    const int sh = 6 - 6 * d;
+    const unsigned c = (key >> sh) & 63u;
+    if (d + 1 == round) {
+      atomicAdd(&lds->b.nhist[k - cur_lo][c], kOne | (unsigned long long)(key & ((1u << sh) - 1u)));
+      return;
+    }
+    ce = lds->b.centry[k][c];
+  }
+}
+
+// The refinement of all flagged level-1 bins.  `each_key(f)` calls f(i, key) for every sub-sampled key the calling
+// lane holds in registers (i = its compile-time index, kNoKey = padding); it is used for round 0 only: the
+// flagged bins' keys are histogrammed over their next 6 bits straight from the registers and copied (15-20 % of
+// the row's keys) to an LDS list; the later rounds walk the list, so the key registers are dead before the
+// wave-level routines run.  NK = keys per lane.
+template <int NK, class EachKey>
+static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n, unsigned tflag, bool ternary, Best best,
+                                                EachKey each_key) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->b.role)[i] = 0u;
+  for (int i = tid; i < kNodeCap * 64; i += kThreads) (&lds->b.centry[0][0])[i] = 0u;
+  for (unsigned i = tid; i < tflag * 64u; i += kThreads) (&lds->b.nhist[0][0])[i] = 0ull;
+  if (tid == 0) {
+    lds->n_nodes = tflag;
+    lds->n_tasks = 0;
+    lds->n_cells = tflag;
+    lds->arena_fill = 0;
+    lds->n_slow = 0;
+    lds->n_list = 0;
+    lds->slow_mask = 0ull;
+  }
+  __syncthreads();
+  if (wid == 0) {
+    // bins whose keys no longer fit the list go to the block path (ascending bin order; tflag <= kFastSlots <= 64)
+    const Slot1 sl = lds->slot[min((unsigned)lane, tflag - 1u)];
+    const unsigned cn = (unsigned)lane < tflag ? sl.cnt : 0u;
+    const unsigned incl = wave_incl_scan(cn);
+    if ((unsigned)lane < tflag) {
+      Node nd;
+      nd.prefix = sl.bin;
+      nd.cnt = sl.cnt;
+      nd.r0 = sl.r0;
+      nd.cell = (unsigned)lane;
+      nd.p0 = sl.p0;
+      nd.root = (unsigned)lane;
+      nd.pad = 0;
+      lds->node[lane] = nd;
+      lds->cell[lane] = kNoKey;
+      if (incl <= (unsigned)kListCap) {
+        reinterpret_cast<unsigned char*>(&lds->b.role[sl.bin])[0] = (unsigned char)(lane + 1);
+        if (sl.next_bin != 0xFFFFu) reinterpret_cast<unsigned char*>(&lds->b.role[sl.next_bin])[1] = (unsigned char)(lane + 1);
+      } else {
+        mark_slow(lds, (unsigned)lane);
+      }
+    }
+  }
+  __syncthreads();
+  // round 0 pass, from the registers.  First sweep: table look-ups (independent of each other: many in flight),
+  // node histograms, successor minima, and which keys to keep; ONE list allocation per wave; second sweep: copy.
+  constexpr int NM = (NK + 31) / 32;
+  unsigned keep[NM];
+#pragma unroll
+  for (int q = 0; q < NM; ++q) keep[q] = 0u;
+  unsigned cnt = 0;
+  each_key([&](int i, unsigned key) {
+    const bool valid = (int)key >= 0;
+    const unsigned e = valid ? (unsigned)lds->b.role[key >> L1_SHIFT] : 0u;
+    const unsigned nd = e & 0xFFu, sc = e >> 8;
+    if (sc) atomicMin(&lds->cell[sc - 1u], key);
+    if (nd) {
+      atomicAdd(&lds->b.nhist[nd - 1u][(key >> 12) & 63u], kOne | (unsigned long long)(key & 0xFFFu));
+      keep[i / 32] |= 1u << (i % 32);
+      ++cnt;
+    }
+  });
+  {
+    const unsigned incl = wave_incl_scan(cnt);
+    unsigned base = 0;
+    if (lane == 63) base = atomicAdd(&lds->n_list, incl);
+    base = (unsigned)__shfl((int)base, 63);
+    unsigned pos = base + incl - cnt;
+    each_key([&](int i, unsigned key) {
+      if ((keep[i / 32] >> (i % 32)) & 1u) lds->b.klist[pos++] = key;
+    });
+  }
+  __syncthreads();
+  FMARK(3);
+  const unsigned n_list = lds->n_list;
+  unsigned cur_lo = 0, cur_n = tflag, tp_lo = 0, tp_n = 0;
+  for (int round = 0; round < 4; ++round) {
+    if (round) {
+      for (unsigned i = tid; i < cur_n * 64u; i += kThreads) (&lds->b.nhist[0][0])[i] = 0ull;
+      for (unsigned i = tid; i < tp_n; i += kThreads) lds->task_fill[tp_lo + i] = 0u;
+      __syncthreads();
+      // list pass: the depth-0 look-ups of 8 keys in flight, the (rare) non-zero entries walked one by one
+      constexpr int G = 8;
+      for (unsigned i0 = tid; i0 < n_list; i0 += G * kThreads) {
+        unsigned kk[G], ce[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) kk[g] = lds->b.klist[min(i0 + (unsigned)g * kThreads, n_list - 1u)];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const unsigned nd = (unsigned)lds->b.role[kk[g] >> L1_SHIFT] & 0xFFu;      // (never 0 for a listed key)
+          ce[g] = lds->b.centry[nd - 1u][(kk[g] >> 12) & 63u];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+          if (ce[g] && i0 + (unsigned)g * kThreads < n_list) walk_key(lds, kk[g], ce[g], round, cur_lo);
+      }
+      __syncthreads();
+    }
+    const unsigned items = cur_n + tp_n;
+    for (unsigned it = (unsigned)wid; it < items; it += kWaves) {
+      if (it < cur_n)
+        scan_node(lds, n, cur_lo + it, cur_lo, round, ternary, best);
+      else
+        resolve_task(lds, n, tp_lo + (it - cur_n), ternary, best);
+    }
+    __syncthreads();
+    cur_lo += cur_n;
+    tp_lo += tp_n;
+    cur_n = min(lds->n_nodes, (unsigned)kNodeCap) - cur_lo;
+    tp_n = min(lds->n_tasks, (unsigned)kTaskCap) - tp_lo;
+    if (cur_n == 0u && tp_n == 0u) break;
+  }
+  FMARK(4);
+  return best;
+}
+
+// block argmin (first minimum in sorted order, optimal.py:151) -> lds->v1
+static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    Best o;
+    o.cost = __shfl_xor(best.cost, d);
+    o.order = __shfl_xor(best.order, d);
+    o.value = __shfl_xor(best.value, d);
+    if (better(o, best)) best = o;
+  }
+  if (lane == 0) lds->wbest[wid] = best;
+  __syncthreads();
+  if (wid == 0) {
+    Best r = lds->wbest[lane & (kWaves - 1)];
+#pragma unroll
+    for (int d = kWaves / 2; d > 0; d >>= 1) {
+      Best o;
+      o.cost = __shfl_xor(r.cost, d);
+      o.order = __shfl_xor(r.order, d);
+      o.value = __shfl_xor(r.value, d);
+      if (better(o, r)) r = o;
+    }
+    if (lane == 0) lds->v1 = r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
+  }
+  __syncthreads();
+}
+
+// Everything between the level-1 histogram and v1.  `each_key` as in refine_resident.
+template <int NK, class EachKey>
+static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned minkey,
+                                                 bool ternary, EachKey each_key) {
+  const int tid = threadIdx.x;
+  Best best;
+  best.cost = INFINITY;
+  best.order = kNoKey;
+  best.value = 0.f;
+  // Usual case: <= kFastSlots flagged bins -> on-chip refinement, nothing left for the block path.  Many
+  // crossing bins (hist1 stays intact): every flagged bin through the block path, kSlotCap at a time.  (The
+  // block path sits behind the last use of the resident keys, so they are not live across it.)
+  unsigned tflag = l1_scan(lds, n, 0u, ternary);
+  FMARK(2);
+  unsigned nslot, round0 = 0;
+  bool listed = false;
+  if (tflag <= (unsigned)kFastSlots) {
+    nslot = 0;
+    if (tflag) {
+      best = refine_resident<NK>(lds, n, tflag, ternary, best, each_key);
+      nslot = lds->n_slow;
+      listed = true;
+    }
+    tflag = 0;
+  } else {
+    nslot = min((unsigned)kSlotCap, tflag);
+  }
+#ifndef EXP_NO_SLOW
+  while (nslot) {
+    for (unsigned q = 0; q < nslot; ++q)
+      best = resolve_slot_block(lds, xrow, n, listed ? (unsigned)lds->slow[q] : q, ternary, best);
+    round0 += kSlotCap;
+    if (round0 >= tflag) break;
+    l1_scan(lds, n, round0, ternary);
+    nslot = min((unsigned)kSlotCap, tflag - round0);
+  }
+#endif
+  // ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
+  if (ternary && n > 0u && tid == 0) {
+    const double mean = lds->total / (double)n;
+    if ((double)key_value(minkey) > 0.5 * mean) {
+      const float half = (float)((double)((float)mean) / 2.0);
+      Best c;
+      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, lds->total, true);
+      c.order = n + 1u;
+      c.value = half;
+      if (better(c, best)) best = c;
+    }
+  }
+  block_argmin(lds, best);
+  return lds->v1;
+}
+
+static __device__ __forceinline__ unsigned block_min(unsigned v, FusedLds* lds) {
+  v = wave_min(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds->wa[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned m = kNoKey;
+  for (int w = 0; w < kWaves; ++w) m = min(m, lds->wa[w]);
+  return m;
+}
+
+static __device__ __forceinline__ void hist_add(FusedLds* lds, unsigned key) {
+  atomicAdd(&lds->a.hist1[key >> L1_SHIFT], kOne | (unsigned long long)(key & ((1u << L1_SHIFT) - 1u)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel body.  Pass 1 = flat walk over the row (three consecutive float4 per lane and step: the
+// sub-sampled elements flat % 3 == 0 are always .x and .w of the first, .z of the second, .y of the third):
+// level-1 histogram, the keys kept in registers.  Solve.  Pass 2 = lane = VEC pixels x 64 channels sweep that
+// packs both planes and sums |x - v1 b1| (quantization.py:84-92, :112-115); for the short rows this second
+// read is served by the L2 / Infinity Cache the first one filled.
+template <int U, int VEC>
+static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
+  FMARK(0);
+  for (int i = tid; i < L1_BINS; i += kThreads) lds->a.hist1[i] = 0ull;
+  if (tid == 0) lds->args = a;
+  __syncthreads();
+
+  const int HW = a.H * a.W;
+  const long long M = a.row_elems;
+  const bool affine = a.pre_scale != nullptr;
+  unsigned kreg[4 * U];
+  unsigned mk = kNoKey;
+  {
+    const float4* __restrict__ row4 = reinterpret_cast<const float4*>(xrow);
+    const unsigned nvec = (unsigned)(M / 4);
+    const unsigned ntrip = (nvec + 2u) / 3u;
+    const float hinv = 1.0f / (float)HW;
+    constexpr int B = 3;                               // triples in flight per lane
+#pragma unroll
+    for (int u0 = 0; u0 < U; u0 += B) {
+      float4 v[B][3];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (u0 + b < U) {
+          const unsigned jt = (unsigned)tid + (unsigned)(u0 + b) * kThreads;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) v[b][t] = row4[min(3u * jt + (unsigned)t, nvec - 1u)];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (u0 + b < U) {
+          const unsigned jt = (unsigned)tid + (unsigned)(u0 + b) * kThreads;
+          const unsigned e0 = 12u * jt;
+          float xs[4] = {v[b][0].x, v[b][0].w, v[b][1].z, v[b][2].y};
+          if (affine) {
+            // channel of element e0 (e0 / HW via a reciprocal, corrected); the other three are at most one
+            // channel boundary further each (HW >= 4)
+            const unsigned ec = min(e0, (unsigned)(M - 1));
+            unsigned c = (unsigned)((float)ec * hinv);
+            if ((c + 1u) * (unsigned)HW <= ec) ++c;
+            if (c * (unsigned)HW > ec) --c;
+            unsigned r = ec - c * (unsigned)HW;        // position inside the channel
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned ce = min(c, (unsigned)a.C - 1u);
+              xs[e] = fmaf(xs[e], a.pre_scale[ce], a.pre_shift[ce]);
+              r += 3u;
+              if (r >= (unsigned)HW) {
+                r -= (unsigned)HW;
+                ++c;
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool has = jt < ntrip && (long long)e0 + 3 * e < M;
+            const unsigned key = abs_key(clamp_sym(xs[e], a.alpha));
+            if (has) {
+              hist_add(lds, key);
+              mk = min(mk, key);
+            }
+            kreg[4 * (u0 + b) + e] = has ? key : kNoKey;
+          }
+        }
+      }
+    }
+  }
+  const unsigned minkey = block_min(mk, lds);      // (its barriers also close the histogram)
+  FMARK(1);
+  const unsigned n = (unsigned)((M + 2) / 3);
+  const bool ternary = a.ternary != 0;
+  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, ternary, [&](auto f) {
+#pragma unroll
+    for (int i = 0; i < 4 * U; ++i) f(i, kreg[i]);
+  });
+
+  FMARK(5);
+  // pass 2: both planes and sum |x - v1 b1|
+  const int PV = (HW + VEC - 1) / VEC;
+  const int items = a.Gt * PV;
+  unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
+  unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
+  double acc = 0.0;
+  for (int item = tid; item < items; item += kThreads) {
+    const int j = item / PV;
+    const int p = (item - j * PV) * VEC;
+    const int grp = j / a.Gg;
+    const int jj = j - grp * a.Gg;
+    const int c0 = grp * a.cg + jj * 64;
+    const int nch = min(64, a.cg - jj * 64);
+    const float* __restrict__ src = xrow + (long long)c0 * HW + p;
+    unsigned long long w0[VEC], w1[VEC];
+    float facc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      w0[v] = w1[v] = 0ull;
+      facc[v] = 0.f;
+    }
+    constexpr int UB = 32 / VEC;                       // independent loads issued before any is consumed
+    for (int cb = 0; cb < nch; cb += UB) {
+      float vals[UB][VEC];
+      float scs[UB], shs[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int cc = min(cb + u, nch - 1);
+        if constexpr (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src + (long long)cc * HW);
+          vals[u][0] = t.x; vals[u][1 % VEC] = t.y; vals[u][2 % VEC] = t.z; vals[u][3 % VEC] = t.w;
+        } else if constexpr (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(src + (long long)cc * HW);
+          vals[u][0] = t.x; vals[u][1 % VEC] = t.y;
+        } else {
+          vals[u][0] = src[(long long)cc * HW];
+        }
+        scs[u] = affine ? a.pre_scale[c0 + cc] : 1.f;
+        shs[u] = affine ? a.pre_shift[c0 + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int cc = cb + u;
+        if (cc < nch) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float xv = clamp_sym(affine ? fmaf(vals[u][v], scs[u], shs[u]) : vals[u][v], a.alpha);
+            const bool b0 = xv >= 0.f;
+            const float r = xv - (b0 ? v1 : -v1);      // x - v1*b1: one rounding, as the reference
+            w0[v] |= (unsigned long long)b0 << cc;
+            w1[v] |= (unsigned long long)(r >= 0.f) << cc;
+            facc[v] += fabsf(r);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc += (double)facc[v];
+      const int pix = p + v;
+      const int h = pix / a.W;
+      const int w = pix - h * a.W;
+      const long long widx = ((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w;
+      prow0[widx] = w0[v];
+      prow1[widx] = w1[v];
+    }
+  }
+  const double tot = block_sum(acc, lds);
+  FMARK(6);
+  if (tid == 0) {
+    a.scales[row] = v1;
+    a.scales[(long long)a.N + row] = ternary ? v1 : (float)(tot / (double)M);
+  }
+}
+};  // struct Impl
+
+template <int T, int U, int VEC>
+__global__ __launch_bounds__(T) void aq_fused_kernel(FusedArgs a) {
+  using I = Impl<T>;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(typename I::FusedLds)];
+  I::template run<U, VEC>(a, reinterpret_cast<typename I::FusedLds*>(smem));
+}
+
+template <int T, int U>
+int launch(const FusedArgs& a, int vec, hipStream_t st) {
+  if (vec == 4) hipLaunchKernelGGL((aq_fused_kernel<T, U, 4>), dim3(a.N), dim3(T), 0, st, a);
+  else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2>), dim3(a.N), dim3(T), 0, st, a);
+  else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1>), dim3(a.N), dim3(T), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int fused_act_quant(const FusedArgs& a, hipStream_t st) {
+  const long long HW = (long long)a.H * a.W;
+  const long long M = a.row_elems;
+  if (M + 2 >= (1ll << 31) || M % 4 != 0 || HW < 4 || ((uintptr_t)a.x % 16) != 0) return kFusedNotEligible;
+  constexpr int T = 512;
+  // pass 2: the widest per-lane vector that still gives every lane an item
+  int vec = 1;
+  if (HW % 4 == 0 && (long long)a.Gt * (HW / 4) >= T) vec = 4;
+  else if (HW % 2 == 0 && (long long)a.Gt * (HW / 2) >= T) vec = 2;
+  const long long ntrip = (M / 4 + 2) / 3;
+  const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
+  if (need <= 5) return launch<T, 5>(a, vec, st);
+  if (need <= 9) return launch<T, 9>(a, vec, st);
+  if (need <= 17) return launch<T, 17>(a, vec, st);
+  if (need <= 33) return launch<T, 33>(a, vec, st);
+  return kFusedNotEligible;
+}
+
+#ifdef LSQ_PHASE_CLOCKS
+extern "C" int lsq_debug_read_fused_times(long long* host8192) {
+  return (int)hipMemcpyFromSymbol(host8192, HIP_SYMBOL(g_fused_times), 8192 * sizeof(long long));
+}
+#endif
+
+}  // namespace lsq

@@ -12,7 +12,8 @@ from typing import Optional, Sequence
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'liblsq_hip.so')
+_LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: developer builds, e.g. -DLSQ_PHASE_CLOCKS)
+    os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'lib', 'liblsq_hip.so')
 _lock = threading.Lock()
 _lib = None
 

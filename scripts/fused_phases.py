@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Developer tool: per-phase time line of the single-launch quantizer (needs a -DLSQ_PHASE_CLOCKS build):
+
+    make -C ml-quant_amd/csrc OUTDIR=$PWD/ml-quant_amd/lib_dbg EXTRA=-DLSQ_PHASE_CLOCKS
+    LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_dbg/liblsq_hip.so python scripts/fused_phases.py [--dist gauss]
+
+Marks (100 MHz constant clock, lane 0 of every workgroup): 0 entry, 1 pass 1 + histogram done, 2 level-1 scan done,
+3 round-0 pass (registers -> node histograms + key list) done, 4 refinement done, 5 v1 known, 6 pass 2 done.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'ml-quant_amd')]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from quant import _hip  # noqa: E402
+
+SHAPES = [(64, 56), (128, 28), (256, 14), (512, 7)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--dist', default='gauss')
+    args = ap.parse_args()
+    lib = _hip.lib()
+    n = args.batch
+    for c, h in SHAPES:
+        x = torch.randn(n, c, h, h, device='cuda')
+        if args.dist != 'gauss':
+            x = x.clamp(min=0)
+        if args.dist == 'relu-bn':
+            x = x * (0.5 + torch.rand(1, c, 1, 1, device='cuda')) * 1.7 + torch.randn(1, c, 1, 1, device='cuda') * 0.5 - 0.7
+        g = _hip.make_geom(n, c, h, h, c, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+        planes = torch.zeros(2 * _hip.act_plane_words(g), dtype=torch.int64, device='cuda')
+        scales = torch.empty((2, n), device='cuda')
+        for _ in range(3):
+            _hip.act_quant(x, g, 2, 2, 3, 3.0, planes, scales)
+        torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * 8192)()
+        lib.lsq_debug_read_fused_times(buf)
+        t = np.array(buf, dtype=np.int64).reshape(1024, 8)[:n, :7].astype(np.float64) / 100.0   # us
+        t0 = t[:, 0].min()
+        d = np.diff(t, axis=1)
+        names = ['pass1', 'l1scan', 'round0', 'refine', 'argmin', 'pass2']
+        print(f'C={c} H={h}: kernel span {t[:, 6].max() - t0:7.1f} us; entry skew {t[:, 0].max() - t0:5.1f} us; per-phase median / max (us): ' +
+              '  '.join(f'{nm} {np.median(d[:, i]):5.1f}/{d[:, i].max():5.1f}' for i, nm in enumerate(names)))
+
+
+if __name__ == '__main__':
+    main()
