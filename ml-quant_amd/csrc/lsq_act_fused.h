@@ -19,6 +19,7 @@ struct FusedArgs {
   float* scales;            // [2][N]
   int N;
   int ternary;
+  int debug;                // developer / test switches: 1 every flagged bin through the block path, 2 a 2048-key list
 };
 
 constexpr int kFusedNotEligible = 1;   // the shape is left to the streaming three-kernel path

@@ -32,7 +32,7 @@
 
 namespace lsq {
 #ifdef LSQ_PHASE_CLOCKS
-__device__ long long g_fused_times[1024][8];    // constant-rate clock (100 MHz) at the phase marks of each workgroup
+__device__ long long g_fused_times[1024][16];    // constant-rate clock (100 MHz) at the phase marks of each workgroup
 #define FMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_fused_times[blockIdx.x][i] = (long long)wall_clock64(); } while (0)
 #else
 #define FMARK(i) do {} while (0)
@@ -46,11 +46,9 @@ constexpr int kNodeCap = 48;                   // nodes over all rounds (round 0
 constexpr int kTaskCap = 256;                  // brute-force tasks over all rounds
 constexpr int kCellCap = kNodeCap + kTaskCap;  // successor cells
 constexpr int kArena = 4096;                   // captured keys of the brute-force tasks
-constexpr int L2_SHIFT = 8, L2_BINS = 1024;    // block path: key bits [17:8]
-constexpr int L3_BINS = 256;                   // block path: key bits [7:0]
-constexpr int kKeysPerLane = L3_BINS / kWave;
 constexpr int kSeg3 = 8;
 constexpr unsigned kTaskBit = 0x8000u;
+constexpr int kBnCap = 1024;                   // channels whose folded batch norm is staged in LDS
 
 struct Node {
   unsigned prefix, cnt, r0, cell;   // key >> (31 - bits); keys; sorted position in front; successor cell
@@ -67,10 +65,6 @@ struct Seg3 {
   unsigned pref, next_pref, cnt, r0;
   double p0;
 };
-struct BlockHists {
-  unsigned long long hist2[L2_BINS];
-  unsigned hist3[kSeg3][L3_BINS];
-};
 
 // Everything below is parameterised by the workgroup size: the per-lane working set of the solver is the same
 // whatever the number of lanes, so FEWER lanes with MORE registers each (512 lanes x 256 VGPRs) leave room for
@@ -79,11 +73,17 @@ template <int kThreads>
 struct Impl {
 static constexpr int kWaves = kThreads / kWave;
 static constexpr int kBinsPerThread = L1_BINS / kThreads;
-static constexpr int kEntries = kNzCap / kThreads;
-#ifndef KGROUP
-#define KGROUP 16
-#endif
-static constexpr int kGroup = KGROUP;      // compact-list entries per lane and chunk
+static constexpr int kEntries = kNzCap / kThreads;      // compact-list entries per lane and chunk
+// block path: one lane per level-2 bin (key bits [17:L2_SHIFT]), level 3 = the remaining low bits
+static constexpr int L2_BINS = kThreads;
+static constexpr int L2_SHIFT = kThreads == 1024 ? 8 : (kThreads == 512 ? 9 : 10);
+static constexpr int L3_BINS = 1 << L2_SHIFT;
+static constexpr int kKeysPerLane = L3_BINS / kWave;
+static_assert((L2_BINS << L2_SHIFT) == (1 << L1_SHIFT), "block path covers the 18 low key bits");
+struct BlockHists {
+  unsigned long long hist2[L2_BINS];
+  unsigned hist3[kSeg3][L3_BINS];
+};
 
 struct FixedLds {
   Slot1 slot[kSlotCap];
@@ -103,6 +103,7 @@ struct FixedLds {
   double total;
   float v1;
   FusedArgs args;
+  float bn_s[kBnCap], bn_t[kBnCap];                // folded batch norm of the row's channels (C <= kBnCap)
 };
 static constexpr int kRefineFixed = 2 * L1_BINS + kNodeCap * 64 * 12 + kArena * 4;   // role, succ, nhist, centry, arena
 static constexpr int kListCap = ((160 * 1024 - (int)sizeof(FixedLds) - kRefineFixed) / 4) & ~63;   // keys of the flagged bins
@@ -199,6 +200,7 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
   double esum = my_sum, total;
   block_excl_scan(enz, ecnt, esum, tnz, tcnt, total, lds);
   if (tid == 0) lds->total = total;
+  FMARK(2);
   unsigned flag_base = 0;                       // flagged bins in front of the current chunk
   for (unsigned chunk = 0; chunk < tnz; chunk += kNzCap) {
     if (chunk) __syncthreads();                 // the previous chunk's prefixes are done with
@@ -223,6 +225,7 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
       }
     }
     __syncthreads();
+    FMARK(3);
     // entry zl = e * kThreads + tid: with the usual few hundred non-empty bins every lane tests at most one
     for (int e = 0; e < kEntries && chunk + (unsigned)e * kThreads < tnz; ++e) {
       const unsigned zl = (unsigned)e * kThreads + (unsigned)tid, z = chunk + zl;
@@ -251,7 +254,7 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
         sl.cnt = cn;
         sl.r0 = lds->a.nz_r0[zl];
         sl.succ = kNoKey;
-        sl.base = 0;
+        sl.base = z + 1 < tnz ? (unsigned)(hist1[nzl[z + 1]] >> 42) : 0u;   // keys in the next non-empty bin
         sl.pad = 0;
         sl.p0 = lds->a.nz_p0[zl];
         sl.sum = sm;
@@ -347,8 +350,8 @@ static __device__ __forceinline__ Best resolve_slot_block(FusedLds* lds, const f
     __syncthreads();
     if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
       Seg3 g;
-      g.pref = (s1_bin << 10) | (unsigned)tid;
-      g.next_pref = next_sub != kNoKey ? ((s1_bin << 10) | next_sub) : kNoKey;
+      g.pref = (s1_bin << (L1_SHIFT - L2_SHIFT)) | (unsigned)tid;
+      g.next_pref = next_sub != kNoKey ? ((s1_bin << (L1_SHIFT - L2_SHIFT)) | next_sub) : kNoKey;
       g.cnt = c2;
       g.r0 = r02;
       g.p0 = p02;
@@ -613,14 +616,14 @@ static __device__ __forceinline__ void walk_key(FusedLds* lds, unsigned key, uns
   }
 }
 
-// The refinement of all flagged level-1 bins.  `each_key(f)` calls f(i, key) for every sub-sampled key the calling
-// lane holds in registers (i = its compile-time index, kNoKey = padding); it is used for round 0 only: the
-// flagged bins' keys are histogrammed over their next 6 bits straight from the registers and copied (15-20 % of
-// the row's keys) to an LDS list; the later rounds walk the list, so the key registers are dead before the
-// wave-level routines run.  NK = keys per lane.
-template <int NK, class EachKey>
+// The refinement of all flagged level-1 bins.  kreg = the sub-sampled keys the calling lane holds in registers
+// (kNoKey = padding).  They are used ONCE: the keys of the flagged bins and of the bins right above them (15-20 %
+// of the row's keys) are copied to an LDS list -- table look-ups in groups of 16 independent loads, one list
+// allocation per wave -- and everything after that walks the list, so the key registers are dead before the
+// histogram atomics and the wave-level routines run.
+template <int NK>
 static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n, unsigned tflag, bool ternary, Best best,
-                                                EachKey each_key) {
+                                                const unsigned (&kreg)[NK]) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->b.role)[i] = 0u;
   for (int i = tid; i < kNodeCap * 64; i += kThreads) (&lds->b.centry[0][0])[i] = 0u;
@@ -636,10 +639,16 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
   }
   __syncthreads();
   if (wid == 0) {
-    // bins whose keys no longer fit the list go to the block path (ascending bin order; tflag <= kFastSlots <= 64)
+    // bins whose keys no longer fit the list go to the block path (ascending bin order; tflag <= kFastSlots <= 64).
+    // A listed bin brings the bin right above it along (its smallest key is the bin's successor): 2 x cnt bounds it.
     const Slot1 sl = lds->slot[min((unsigned)lane, tflag - 1u)];
     const unsigned cn = (unsigned)lane < tflag ? sl.cnt : 0u;
-    const unsigned incl = wave_incl_scan(cn);
+    // Listed: the bin's keys and those of the next non-empty bin (the successor of the bin's largest key is the
+    // smallest key up there).  Cumulative distinct keys: the next bin counts once when it is flagged itself.
+    const unsigned above = (unsigned)__shfl_down((int)(unsigned)sl.bin, 1);        // the next flagged bin
+    const bool next_flagged = (unsigned)lane + 1u < tflag && above == (unsigned)sl.next_bin;
+    const unsigned nb = (unsigned)lane < tflag && !next_flagged ? sl.base : 0u;
+    const unsigned incl = wave_incl_scan(cn + nb) + ((unsigned)lane < tflag && next_flagged ? sl.base : 0u);
     if ((unsigned)lane < tflag) {
       Node nd;
       nd.prefix = sl.bin;
@@ -651,7 +660,7 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
       nd.pad = 0;
       lds->node[lane] = nd;
       lds->cell[lane] = kNoKey;
-      if (incl <= (unsigned)kListCap) {
+      if (incl <= ((lds->args.debug & 2) ? 2048u : (unsigned)kListCap)) {
         reinterpret_cast<unsigned char*>(&lds->b.role[sl.bin])[0] = (unsigned char)(lane + 1);
         if (sl.next_bin != 0xFFFFu) reinterpret_cast<unsigned char*>(&lds->b.role[sl.next_bin])[1] = (unsigned char)(lane + 1);
       } else {
@@ -660,36 +669,40 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
     }
   }
   __syncthreads();
-  // round 0 pass, from the registers.  First sweep: table look-ups (independent of each other: many in flight),
-  // node histograms, successor minima, and which keys to keep; ONE list allocation per wave; second sweep: copy.
-  constexpr int NM = (NK + 31) / 32;
+  // register sweep 1: which keys to keep
+  constexpr int NM = (NK + 31) / 32, G = 16;
   unsigned keep[NM];
 #pragma unroll
   for (int q = 0; q < NM; ++q) keep[q] = 0u;
   unsigned cnt = 0;
-  each_key([&](int i, unsigned key) {
-    const bool valid = (int)key >= 0;
-    const unsigned e = valid ? (unsigned)lds->b.role[key >> L1_SHIFT] : 0u;
-    const unsigned nd = e & 0xFFu, sc = e >> 8;
-    if (sc) atomicMin(&lds->cell[sc - 1u], key);
-    if (nd) {
-      atomicAdd(&lds->b.nhist[nd - 1u][(key >> 12) & 63u], kOne | (unsigned long long)(key & 0xFFFu));
-      keep[i / 32] |= 1u << (i % 32);
-      ++cnt;
+#pragma unroll
+  for (int g0 = 0; g0 < NK; g0 += G) {
+    unsigned ent[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (g0 + g < NK) ent[g] = lds->b.role[(kreg[g0 + g] >> L1_SHIFT) & (L1_BINS - 1)];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g0 + g < NK) {
+        const bool k = ent[g] != 0u && (int)kreg[g0 + g] >= 0;
+        keep[(g0 + g) / 32] |= (k ? 1u : 0u) << ((g0 + g) % 32);
+        cnt += k ? 1u : 0u;
+      }
     }
-  });
+  }
   {
     const unsigned incl = wave_incl_scan(cnt);
     unsigned base = 0;
     if (lane == 63) base = atomicAdd(&lds->n_list, incl);
     base = (unsigned)__shfl((int)base, 63);
     unsigned pos = base + incl - cnt;
-    each_key([&](int i, unsigned key) {
-      if ((keep[i / 32] >> (i % 32)) & 1u) lds->b.klist[pos++] = key;
-    });
+    // register sweep 2: copy
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+      if ((keep[i / 32] >> (i % 32)) & 1u) lds->b.klist[pos++] = kreg[i];
   }
   __syncthreads();
-  FMARK(3);
+  FMARK(5);
   const unsigned n_list = lds->n_list;
   unsigned cur_lo = 0, cur_n = tflag, tp_lo = 0, tp_n = 0;
   for (int round = 0; round < 4; ++round) {
@@ -697,23 +710,40 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
       for (unsigned i = tid; i < cur_n * 64u; i += kThreads) (&lds->b.nhist[0][0])[i] = 0ull;
       for (unsigned i = tid; i < tp_n; i += kThreads) lds->task_fill[tp_lo + i] = 0u;
       __syncthreads();
-      // list pass: the depth-0 look-ups of 8 keys in flight, the (rare) non-zero entries walked one by one
-      constexpr int G = 8;
-      for (unsigned i0 = tid; i0 < n_list; i0 += G * kThreads) {
-        unsigned kk[G], ce[G];
+    }
+    // list pass: the table look-ups of 8 keys in flight.  Round 0: every key of a flagged bin into its node's
+    // histogram, keys of a successor bin into the cell minimum.  Later rounds: the (rare) non-zero depth-0 entries
+    // are walked one by one.
+    constexpr int LG = 8;
+    for (unsigned i0 = tid; i0 < n_list; i0 += LG * kThreads) {
+      unsigned kk[LG], ce[LG];
 #pragma unroll
-        for (int g = 0; g < G; ++g) kk[g] = lds->b.klist[min(i0 + (unsigned)g * kThreads, n_list - 1u)];
+      for (int g = 0; g < LG; ++g) kk[g] = lds->b.klist[min(i0 + (unsigned)g * kThreads, n_list - 1u)];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const unsigned nd = (unsigned)lds->b.role[kk[g] >> L1_SHIFT] & 0xFFu;      // (never 0 for a listed key)
-          ce[g] = lds->b.centry[nd - 1u][(kk[g] >> 12) & 63u];
+      for (int g = 0; g < LG; ++g) ce[g] = lds->b.role[kk[g] >> L1_SHIFT];
+      if (round == 0) {
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {
+          if (i0 + (unsigned)g * kThreads < n_list) {
+            const unsigned nd = ce[g] & 0xFFu, sc = ce[g] >> 8;
+            if (sc) atomicMin(&lds->cell[sc - 1u], kk[g]);
+            if (nd) atomicAdd(&lds->b.nhist[nd - 1u][(kk[g] >> 12) & 63u], kOne | (unsigned long long)(kk[g] & 0xFFFu));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < LG; ++g) {
+          const unsigned nd = ce[g] & 0xFFu;
+          ce[g] = nd ? lds->b.centry[nd - 1u][(kk[g] >> 12) & 63u] : 0u;
         }
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int g = 0; g < LG; ++g)
           if (ce[g] && i0 + (unsigned)g * kThreads < n_list) walk_key(lds, kk[g], ce[g], round, cur_lo);
       }
-      __syncthreads();
     }
+    __syncthreads();
+    if (round == 0) FMARK(6);
+    if (round == 1) FMARK(11);
     const unsigned items = cur_n + tp_n;
     for (unsigned it = (unsigned)wid; it < items; it += kWaves) {
       if (it < cur_n)
@@ -722,13 +752,22 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
         resolve_task(lds, n, tp_lo + (it - cur_n), ternary, best);
     }
     __syncthreads();
+    if (round == 0) FMARK(7);
+    if (round == 1) FMARK(12);
     cur_lo += cur_n;
     tp_lo += tp_n;
     cur_n = min(lds->n_nodes, (unsigned)kNodeCap) - cur_lo;
     tp_n = min(lds->n_tasks, (unsigned)kTaskCap) - tp_lo;
     if (cur_n == 0u && tp_n == 0u) break;
   }
-  FMARK(4);
+  FMARK(8);
+#ifdef LSQ_PHASE_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_fused_times[blockIdx.x][13] = lds->n_list;
+    g_fused_times[blockIdx.x][14] = lds->n_tasks;
+    g_fused_times[blockIdx.x][15] = lds->n_nodes * 1000 + tflag;
+  }
+#endif
   return best;
 }
 
@@ -761,9 +800,9 @@ static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
 }
 
 // Everything between the level-1 histogram and v1.  `each_key` as in refine_resident.
-template <int NK, class EachKey>
+template <int NK>
 static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned minkey,
-                                                 bool ternary, EachKey each_key) {
+                                                 bool ternary, const unsigned (&kreg)[NK]) {
   const int tid = threadIdx.x;
   Best best;
   best.cost = INFINITY;
@@ -773,13 +812,13 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
   // crossing bins (hist1 stays intact): every flagged bin through the block path, kSlotCap at a time.  (The
   // block path sits behind the last use of the resident keys, so they are not live across it.)
   unsigned tflag = l1_scan(lds, n, 0u, ternary);
-  FMARK(2);
+  FMARK(4);
   unsigned nslot, round0 = 0;
   bool listed = false;
-  if (tflag <= (unsigned)kFastSlots) {
+  if (tflag <= (unsigned)kFastSlots && !(lds->args.debug & 1)) {
     nslot = 0;
     if (tflag) {
-      best = refine_resident<NK>(lds, n, tflag, ternary, best, each_key);
+      best = refine_resident<NK>(lds, n, tflag, ternary, best, kreg);
       nslot = lds->n_slow;
       listed = true;
     }
@@ -828,6 +867,189 @@ static __device__ __forceinline__ void hist_add(FusedLds* lds, unsigned key) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pass 2.  Per element: bit0 = x >= 0 (sign(+-0) = +1, ste.py:16-18), r = xc - v1*b1 with xc the clamped value,
+// bit1 = r >= 0, and |r| for the second scale (quantization.py:84-92).  With d = min(|x|, alpha) - v1:
+// r = d for b1 = +1 and r = -d for b1 = -1 EXACTLY (|xc| - v1 and xc -+ v1 round the same way), so
+// bit1 = ((b0 ? d : -d) >= 0) and |r| = |d|.  The two compares go straight from VCC into the plane words with
+// v_addc_co_u32 (w = 2 w + carry-in): one VALU instruction per packed bit; channels ascending, so the words
+// come out bit-reversed and one v_bfrev_b32 per 32 channels fixes that.
+static __device__ __forceinline__ void push_bits(unsigned& w0, unsigned& w1, float& facc, float x, float d) {
+  float t;
+  // (the |d| accumulation sits in the same block: left to the scheduler, all 64 channels' adds sink to the end of
+  // the item and their operands spill)
+  asm volatile(
+      "v_cmp_le_f32 vcc, 0, %[x]\n\t"
+      "v_cndmask_b32_e64 %[t], -%[d], %[d], vcc\n\t"
+      "v_addc_co_u32_e32 %[w0], vcc, %[w0], %[w0], vcc\n\t"
+      "v_cmp_le_f32 vcc, 0, %[t]\n\t"
+      "v_addc_co_u32_e32 %[w1], vcc, %[w1], %[w1], vcc\n\t"
+      "v_add_f32_e64 %[f], %[f], |%[d]|"
+      : [w0] "+v"(w0), [w1] "+v"(w1), [f] "+v"(facc), [t] "=&v"(t)
+      : [x] "v"(x), [d] "v"(d)
+      : "vcc");
+}
+
+// full 64-channel groups: every channel index is a compile-time constant
+template <int VEC, bool AFFINE>
+static __device__ __forceinline__ double pass2_full(const FusedArgs& a, FusedLds* lds, const float* __restrict__ xrow, float v1,
+                                                    unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1) {
+  const int tid = threadIdx.x;
+  const int HW = a.H * a.W;
+  const int PV = (HW + VEC - 1) / VEC;
+  const int items = a.Gt * PV;
+  const float alpha = a.alpha >= 0.f ? a.alpha : INFINITY;
+  double acc = 0.0;
+  for (int item = tid; item < items; item += kThreads) {
+    const int j = item / PV;
+    const int p = (item - j * PV) * VEC;
+    const int grp = j / a.Gg;
+    const int jj = j - grp * a.Gg;
+    const int c0 = grp * a.cg + jj * 64;
+    const float* __restrict__ src = xrow + (long long)c0 * HW + p;
+    const float* __restrict__ bs = lds->bn_s + c0;
+    const float* __restrict__ bt = lds->bn_t + c0;
+    unsigned w0[VEC][2], w1[VEC][2];
+    float facc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      w0[v][0] = w0[v][1] = w1[v][0] = w1[v][1] = 0u;
+      facc[v] = 0.f;
+    }
+    constexpr int UB = 32 / VEC;                       // loads per batch; two batches in flight
+    constexpr int NB = 64 / UB;
+    float buf[2][UB][VEC];
+    const float* __restrict__ q = src;                 // running channel pointer (no table of 64 addresses)
+    auto load = [&](int which, int) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u, q += HW) {
+        if constexpr (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(q);
+          buf[which][u][0] = t.x; buf[which][u][1 % VEC] = t.y; buf[which][u][2 % VEC] = t.z; buf[which][u][3 % VEC] = t.w;
+        } else if constexpr (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(q);
+          buf[which][u][0] = t.x; buf[which][u][1 % VEC] = t.y;
+        } else {
+          buf[which][u][0] = *q;
+        }
+      }
+    };
+    load(0, 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      // (the scheduling barriers keep exactly two batches of loads in flight: without them the scheduler hoists all
+      // 64 channels' loads to the top and spills)
+      __builtin_amdgcn_sched_barrier(0);
+      if (b + 1 < NB) load((b + 1) & 1, b + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int cc = b * UB + u;                     // compile-time
+        float sc = 1.f, sh = 0.f;
+        if constexpr (AFFINE) {
+          sc = bs[cc];
+          sh = bt[cc];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float xv = buf[b & 1][u][v];
+          if constexpr (AFFINE) xv = fmaf(xv, sc, sh);
+          const float d = fminf(fabsf(xv), alpha) - v1;
+          push_bits(w0[v][cc >> 5], w1[v][cc >> 5], facc[v], xv, d);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc += (double)facc[v];
+      const int pix = p + v;
+      if (pix < HW) {
+        const int h = pix / a.W;
+        const int w = pix - h * a.W;
+        const long long widx = ((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w;
+        prow0[widx] = (unsigned long long)__brev(w0[v][0]) | ((unsigned long long)__brev(w0[v][1]) << 32);
+        prow1[widx] = (unsigned long long)__brev(w1[v][0]) | ((unsigned long long)__brev(w1[v][1]) << 32);
+      }
+    }
+  }
+  return acc;
+}
+
+// any channel count (groups that are not multiples of 64: LeNet's 20 channels, grouped convolutions)
+template <int VEC>
+static __device__ __forceinline__ double pass2_any(const FusedArgs& a, const float* __restrict__ xrow, float v1,
+                                                   unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1) {
+  const int tid = threadIdx.x;
+  const int HW = a.H * a.W;
+  const int PV = (HW + VEC - 1) / VEC;
+  const int items = a.Gt * PV;
+  const bool affine = a.pre_scale != nullptr;
+  double acc = 0.0;
+  for (int item = tid; item < items; item += kThreads) {
+    const int j = item / PV;
+    const int p = (item - j * PV) * VEC;
+    const int grp = j / a.Gg;
+    const int jj = j - grp * a.Gg;
+    const int c0 = grp * a.cg + jj * 64;
+    const int nch = min(64, a.cg - jj * 64);
+    const float* __restrict__ src = xrow + (long long)c0 * HW + p;
+    unsigned long long w0[VEC], w1[VEC];
+    float facc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      w0[v] = w1[v] = 0ull;
+      facc[v] = 0.f;
+    }
+    constexpr int UB = 8;
+    for (int cb = 0; cb < nch; cb += UB) {
+      float vals[UB][VEC], scs[UB], shs[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int cc = min(cb + u, nch - 1);
+        if constexpr (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src + (long long)cc * HW);
+          vals[u][0] = t.x; vals[u][1 % VEC] = t.y; vals[u][2 % VEC] = t.z; vals[u][3 % VEC] = t.w;
+        } else if constexpr (VEC == 2) {
+          const float2 t = *reinterpret_cast<const float2*>(src + (long long)cc * HW);
+          vals[u][0] = t.x; vals[u][1 % VEC] = t.y;
+        } else {
+          vals[u][0] = src[(long long)cc * HW];
+        }
+        scs[u] = affine ? a.pre_scale[c0 + cc] : 1.f;
+        shs[u] = affine ? a.pre_shift[c0 + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int cc = cb + u;
+        if (cc < nch) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float xv = clamp_sym(affine ? fmaf(vals[u][v], scs[u], shs[u]) : vals[u][v], a.alpha);
+            const bool b0 = xv >= 0.f;
+            const float r = xv - (b0 ? v1 : -v1);      // x - v1*b1: one rounding, as the reference
+            w0[v] |= (unsigned long long)b0 << cc;
+            w1[v] |= (unsigned long long)(r >= 0.f) << cc;
+            facc[v] += fabsf(r);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      acc += (double)facc[v];
+      const int pix = p + v;
+      if (pix < HW) {
+        const int h = pix / a.W;
+        const int w = pix - h * a.W;
+        const long long widx = ((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w;
+        prow0[widx] = w0[v];
+        prow1[widx] = w1[v];
+      }
+    }
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The kernel body.  Pass 1 = flat walk over the row (three consecutive float4 per lane and step: the
 // sub-sampled elements flat % 3 == 0 are always .x and .w of the first, .z of the second, .y of the third):
 // level-1 histogram, the keys kept in registers.  Solve.  Pass 2 = lane = VEC pixels x 64 channels sweep that
@@ -841,6 +1063,12 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   FMARK(0);
   for (int i = tid; i < L1_BINS; i += kThreads) lds->a.hist1[i] = 0ull;
   if (tid == 0) lds->args = a;
+  if (a.pre_scale != nullptr && a.C <= kBnCap) {
+    for (int i = tid; i < a.C; i += kThreads) {
+      lds->bn_s[i] = a.pre_scale[i];
+      lds->bn_t[i] = a.pre_shift[i];
+    }
+  }
   __syncthreads();
 
   const int HW = a.H * a.W;
@@ -908,81 +1136,20 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   FMARK(1);
   const unsigned n = (unsigned)((M + 2) / 3);
   const bool ternary = a.ternary != 0;
-  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, ternary, [&](auto f) {
-#pragma unroll
-    for (int i = 0; i < 4 * U; ++i) f(i, kreg[i]);
-  });
+  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, ternary, kreg);
 
-  FMARK(5);
+  FMARK(9);
   // pass 2: both planes and sum |x - v1 b1|
-  const int PV = (HW + VEC - 1) / VEC;
-  const int items = a.Gt * PV;
   unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
   unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
-  double acc = 0.0;
-  for (int item = tid; item < items; item += kThreads) {
-    const int j = item / PV;
-    const int p = (item - j * PV) * VEC;
-    const int grp = j / a.Gg;
-    const int jj = j - grp * a.Gg;
-    const int c0 = grp * a.cg + jj * 64;
-    const int nch = min(64, a.cg - jj * 64);
-    const float* __restrict__ src = xrow + (long long)c0 * HW + p;
-    unsigned long long w0[VEC], w1[VEC];
-    float facc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      w0[v] = w1[v] = 0ull;
-      facc[v] = 0.f;
-    }
-    constexpr int UB = 32 / VEC;                       // independent loads issued before any is consumed
-    for (int cb = 0; cb < nch; cb += UB) {
-      float vals[UB][VEC];
-      float scs[UB], shs[UB];
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int cc = min(cb + u, nch - 1);
-        if constexpr (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(src + (long long)cc * HW);
-          vals[u][0] = t.x; vals[u][1 % VEC] = t.y; vals[u][2 % VEC] = t.z; vals[u][3 % VEC] = t.w;
-        } else if constexpr (VEC == 2) {
-          const float2 t = *reinterpret_cast<const float2*>(src + (long long)cc * HW);
-          vals[u][0] = t.x; vals[u][1 % VEC] = t.y;
-        } else {
-          vals[u][0] = src[(long long)cc * HW];
-        }
-        scs[u] = affine ? a.pre_scale[c0 + cc] : 1.f;
-        shs[u] = affine ? a.pre_shift[c0 + cc] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int cc = cb + u;
-        if (cc < nch) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float xv = clamp_sym(affine ? fmaf(vals[u][v], scs[u], shs[u]) : vals[u][v], a.alpha);
-            const bool b0 = xv >= 0.f;
-            const float r = xv - (b0 ? v1 : -v1);      // x - v1*b1: one rounding, as the reference
-            w0[v] |= (unsigned long long)b0 << cc;
-            w1[v] |= (unsigned long long)(r >= 0.f) << cc;
-            facc[v] += fabsf(r);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      acc += (double)facc[v];
-      const int pix = p + v;
-      const int h = pix / a.W;
-      const int w = pix - h * a.W;
-      const long long widx = ((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w;
-      prow0[widx] = w0[v];
-      prow1[widx] = w1[v];
-    }
+  double acc;
+  if ((a.cg & 63) == 0 && a.C <= kBnCap) {
+    acc = affine ? pass2_full<VEC, true>(a, lds, xrow, v1, prow0, prow1) : pass2_full<VEC, false>(a, lds, xrow, v1, prow0, prow1);
+  } else {
+    acc = pass2_any<VEC>(a, xrow, v1, prow0, prow1);
   }
   const double tot = block_sum(acc, lds);
-  FMARK(6);
+  FMARK(10);
   if (tid == 0) {
     a.scales[row] = v1;
     a.scales[(long long)a.N + row] = ternary ? v1 : (float)(tot / (double)M);
@@ -1018,6 +1185,11 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
   else if (HW % 2 == 0 && (long long)a.Gt * (HW / 2) >= T) vec = 2;
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
+#ifdef EXP_T1024
+  if (need <= 2) return launch<1024, 3>(a, vec, st);
+  if (need <= 4) return launch<1024, 5>(a, vec, st);
+  if (need <= 8) return launch<1024, 9>(a, vec, st);
+#endif
   if (need <= 5) return launch<T, 5>(a, vec, st);
   if (need <= 9) return launch<T, 9>(a, vec, st);
   if (need <= 17) return launch<T, 17>(a, vec, st);
@@ -1026,8 +1198,8 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
 }
 
 #ifdef LSQ_PHASE_CLOCKS
-extern "C" int lsq_debug_read_fused_times(long long* host8192) {
-  return (int)hipMemcpyFromSymbol(host8192, HIP_SYMBOL(g_fused_times), 8192 * sizeof(long long));
+extern "C" int lsq_debug_read_fused_times(long long* host16384) {
+  return (int)hipMemcpyFromSymbol(host16384, HIP_SYMBOL(g_fused_times), 16384 * sizeof(long long));
 }
 #endif
 

@@ -1678,10 +1678,17 @@ using namespace lsq;
 
 // developer / test switch: 1 forces the streaming three-kernel path for every shape (the fused single-launch
 // path is otherwise taken whenever the row fits); not part of the public header
-static int g_force_streaming = 0;
+static int g_force_streaming = 0, g_fused_debug = 0;
 extern "C" int lsq_debug_force_streaming(int on) {
   const int old = g_force_streaming;
   g_force_streaming = on;
+  return old;
+}
+// rare paths of the single-launch quantizer on ordinary data: 1 = every flagged bin through its block path,
+// 2 = key list of 2048 entries (most bins overflow to the block path)
+extern "C" int lsq_debug_fused_mode(int mode) {
+  const int old = g_fused_debug;
+  g_fused_debug = mode;
   return old;
 }
 
@@ -1742,7 +1749,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     f.pad_h = a.pad_h; f.pad_w = a.pad_w;
     f.alpha = clamp_alpha; f.pre_scale = pre_scale; f.pre_shift = pre_shift;
     f.planes = a.planes; f.plane_words = a.plane_words; f.row_words = a.row_words;
-    f.scales = scales; f.N = a.N; f.ternary = a.ternary;
+    f.scales = scales; f.N = a.N; f.ternary = a.ternary; f.debug = g_fused_debug;
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
   }

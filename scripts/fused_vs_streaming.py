@@ -43,11 +43,12 @@ def make(dist, n, c, h, w, gen):
     raise ValueError(dist)
 
 
-def run(x, g, scheme, alpha, pre, force):
+def run(x, g, scheme, alpha, pre, force, mode=0):
     lib = _hip.lib()
     lib.lsq_debug_force_streaming.restype = ctypes.c_int
     lib.lsq_debug_force_streaming.argtypes = [ctypes.c_int]
     old = lib.lsq_debug_force_streaming(1 if force else 0)
+    lib.lsq_debug_fused_mode(mode)
     try:
         planes = torch.zeros(2 * _hip.act_plane_words(g), dtype=torch.int64, device='cuda')
         scales = torch.zeros((2, g.N), device='cuda')
@@ -55,6 +56,7 @@ def run(x, g, scheme, alpha, pre, force):
         torch.cuda.synchronize()
     finally:
         lib.lsq_debug_force_streaming(old)
+        lib.lsq_debug_fused_mode(0)
     return planes, scales
 
 
@@ -75,15 +77,15 @@ def main():
                     if fold:
                         pre = ((0.5 + torch.rand(c, generator=gen, device='cuda')).contiguous(),
                                (torch.randn(c, generator=gen, device='cuda') * 0.3).contiguous())
-                    pf, sf = run(x, g, scheme, alpha, pre, False)
                     ps, ss = run(x, g, scheme, alpha, pre, True)
-                    ok = torch.equal(sf, ss) and torch.equal(pf, ps)
-                    if not ok:
-                        bad += 1
-                        dv = (sf - ss).abs().max().item()
-                        nb = (pf != ps).sum().item()
-                        print(f'MISMATCH C={c} H={h} W={w} {dist} scheme={scheme} alpha={alpha} fold={fold}: '
-                              f'max|dscale|={dv:.3e} differing plane words={nb}  fused={sf[:, :3].tolist()} stream={ss[:, :3].tolist()}')
+                    for mode in (0, 1, 2):     # ordinary, every bin through the block path, 2048-key list
+                        pf, sf = run(x, g, scheme, alpha, pre, False, mode)
+                        if not (torch.equal(sf, ss) and torch.equal(pf, ps)):
+                            bad += 1
+                            dv = (sf - ss).abs().max().item()
+                            nb = (pf != ps).sum().item()
+                            print(f'MISMATCH mode={mode} C={c} H={h} W={w} {dist} scheme={scheme} alpha={alpha} fold={fold}: '
+                                  f'max|dscale|={dv:.3e} differing plane words={nb}  fused={sf[:, :3].tolist()} stream={ss[:, :3].tolist()}')
     print('fused_vs_streaming:', 'ALL EQUAL' if bad == 0 else f'{bad} MISMATCHES')
     return 1 if bad else 0
 
