@@ -1,31 +1,34 @@
 // Single-launch LS-2 / LS-T activation quantizer for gfx950 (quant/binary/quantization.py:59-115 +
 // quant/binary/optimal.py:41-155 behind QuantConv2d.forward, binary_conv.py:161-164).
 //
-// One workgroup owns one row (one sample).  What the streaming path (lsq_act_quant.hip) hands
-// from kernel to kernel through HBM stays on chip here:
+// One 512-thread workgroup owns one row (one sample) from the first load to the last plane word; the streaming
+// path (lsq_act_quant.hip) needs three kernels and three reads of the row for the same work.
 //
-//   * rows of at most 1024 (channel-group, pixel) items -- the 14x14 and 7x7 layers of ResNet-18, every layer of
-//     the CIFAR network, LeNet -- are read ONCE: a lane keeps the 64 clamped channel values of its pixel in
-//     registers, packs plane 0, feeds the solver from the registers and packs plane 1 / sums |x - v1 b1| from
-//     them again (1x the algorithmic traffic, one launch);
-//   * longer rows (28x28: 33 451 sub-sampled keys, 56x56: 66 902) are read TWICE: a flat coalesced walk that
-//     keeps the row's sub-sampled keys in registers (4 keys per 3 float4 loads; <= 68 registers per lane), the
-//     solve from those registers, then one lane = 4-pixel sweep that packs both planes and the second scale.
-//     The streaming path's third read (the solve's gather) is gone.
+//   pass 1   flat coalesced walk over the row (three consecutive float4 per lane and step: the sub-sampled elements
+//            flat % 3 == 0 are .x and .w of the first, .z of the second, .y of the third): folded batch norm (from
+//            an LDS copy of scale / shift), clamp, one 64-bit LDS atomic per key into the 13-bit level-1 histogram
+//            (count | exact sum of the low key bits), and the KEYS STAY IN REGISTERS (132 per lane at 56x56).
+//   solve    level-1 scan over the occupied bin range -> the ~10 bins that can hold a candidate (optimal.py:78-80);
+//            their keys (15-20 % of the row's) are copied from the registers to an LDS list (ballot + mbcnt, one
+//            list allocation per wave and 16 keys); the refinement then works on the list: per round every node
+//            (a key prefix of 13 / 19 / 25 bits) is histogrammed over its next 6 bits, one wave scans a node's
+//            64 children, flagged children become an analytic run (all keys equal), a brute-force task (<= 64
+//            keys, captured into an LDS arena and ranked from LDS broadcast reads) or a node of the next round.
+//            Same exact arithmetic as the streaming path: integer bin sums, fp64 prefix sums in fixed order,
+//            conservative bin tests, exact candidate tests, closed-form cost, (cost, sorted position) argmin.
+//   pass 2   lane = VEC pixels x 64 channels: both planes and sum |x - v1 b1|; compile-time channel indices,
+//            v_cmp + v_addc_co_u32 bit packing (8 VALU instructions per element), double-buffered loads.
 //
-// The solve is the same exact radix select as the streaming path (13-bit level-1 histogram whose words carry
-// count and the exact integer sum of the low key bits; conservative bin tests; exact fp64 candidate tests;
-// closed-form cost), but the refinement below level 1 works on the resident keys directly: per round every
-// flagged node (a key prefix of 13 / 19 / 25 bits) is histogrammed over its next 6 key bits by ONE pass of all
-// lanes over their registers (table walk role[] -> centry[][] from the key's prefix to its node), one wave per
-// node scans the 64 children, and flagged children become: an analytic run (prefix = whole key), a brute-force
-// task (<= 64 keys: captured into an LDS arena by the next pass and ranked with shuffles) or a node of the
-// next round.  Two passes over the registers (~1 us each) replace the gather sweep over HBM.  Anything the
-// fixed-size tables cannot take (more than 40 flagged level-1 bins, table or list overflow) goes to a block-level
-// path that histograms straight from the row in memory: slow, general, exact.
+// HBM traffic: two reads of the row (the second one of the short rows is served by L2 / Infinity Cache) instead
+// of three, one launch instead of three, no workspace.  Why 512 lanes: the per-lane working set of the solver is
+// the same whatever the number of lanes, so fewer lanes with 256 VGPRs each leave room for the resident keys
+// where 1024 lanes with 128 VGPRs spill; every kernel here has private_segment_fixed_size 0.
+// Anything the fixed-size tables cannot take (more than 40 flagged level-1 bins, table or list overflow) goes to a
+// block-level path that histograms straight from the row in memory: slow, general, exact.
 //
 // Results are bit-identical to the streaming path and to oracle/lsq_exact.py (same candidate set, same
-// closed-form cost, same (cost, sorted position) argmin).
+// closed-form cost, same argmin); scripts/fused_vs_streaming.py and tests/test_gpu_parity.py check it, the rare
+// paths included (lsq_debug_fused_mode).
 
 #include "lsq_act_fused.h"
 #include "lsq_solver_math.h"
@@ -54,6 +57,7 @@ struct Node {
   unsigned prefix, cnt, r0, cell;   // key >> (31 - bits); keys; sorted position in front; successor cell
   double p0;                        // prefix sum in front
   unsigned root, pad;               // level-1 slot it descends from
+  unsigned kmin, kmax;              // nodes below round 0: smallest / largest key (a run of equal keys ends there)
 };
 struct Task {
   double ps;
@@ -66,9 +70,7 @@ struct Seg3 {
   double p0;
 };
 
-// Everything below is parameterised by the workgroup size: the per-lane working set of the solver is the same
-// whatever the number of lanes, so FEWER lanes with MORE registers each (512 lanes x 256 VGPRs) leave room for
-// the resident keys of the longest rows (132 registers per lane at 56x56) where 1024 lanes x 128 VGPRs do not.
+// Everything below is parameterised by the workgroup size.
 template <int kThreads>
 struct Impl {
 static constexpr int kWaves = kThreads / kWave;
@@ -98,14 +100,14 @@ struct FixedLds {
   unsigned wa[kWaves], wb[kWaves], wc[kWaves];
   double ws[kWaves];
   Best wbest[kWaves];
-  unsigned n_nodes, n_tasks, n_cells, arena_fill, blk_succ, n_slow, n_list, pad0;
+  unsigned n_nodes, n_tasks, n_cells, arena_fill, blk_succ, n_slow, n_list, maxkey;
   unsigned long long slow_mask;
   double total;
   float v1;
   FusedArgs args;
   float bn_s[kBnCap], bn_t[kBnCap];                // folded batch norm of the row's channels (C <= kBnCap)
 };
-static constexpr int kRefineFixed = 2 * L1_BINS + kNodeCap * 64 * 12 + kArena * 4;   // role, succ, nhist, centry, arena
+static constexpr int kRefineFixed = 2 * L1_BINS + 8 + kNodeCap * 64 * 12 + kArena * 4;   // role, succ, nhist, centry, arena
 static constexpr int kListCap = ((160 * 1024 - (int)sizeof(FixedLds) - kRefineFixed) / 4) & ~63;   // keys of the flagged bins
 
 struct FusedLds : FixedLds {
@@ -118,8 +120,8 @@ struct FusedLds : FixedLds {
       BlockHists blk;
     } a;
     struct {                                       // on-chip refinement
-      unsigned short role[L1_BINS];                // level-1 bin -> low byte: node + 1; high byte: successor cell + 1 of
-                                                   // the flagged bin below it
+      unsigned short role[L1_BINS + 2];            // level-1 bin -> low byte: node + 1; high byte: successor cell + 1 of
+                                                   // the flagged bin below it; [L1_BINS] = 0 for padding keys
       unsigned long long nhist[kNodeCap][64];      // node histograms of the current round
       unsigned centry[kNodeCap][64];               // low half: child node + 1 or kTaskBit | task; high half: cell + 1
       unsigned arena[kArena];                      // captured keys of the brute-force tasks
@@ -181,20 +183,28 @@ static __device__ __forceinline__ void store_hi16(unsigned* w, unsigned v) { rei
 // runs over the COMPACT list of non-empty bins (they sit in a few binades, i.e. in the bin ranges of a few
 // dozen lanes), kNzCap entries at a time; loops are rolled and per-entry state is re-read from LDS instead of
 // being carried in registers: the resident keys of the caller stay live across this function.
-static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, unsigned round0, bool ternary) {
+static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, unsigned round0, bool ternary, unsigned bin_lo,
+                                                   unsigned bin_hi) {
   const unsigned long long* const hist1 = lds->a.hist1;
   unsigned short* const nzl = lds->a.nzlist;
   const int tid = threadIdx.x;
+  // The keys of a row sit in [bin_lo, bin_hi] (smallest / largest key of pass 1), typically a few hundred bins: the
+  // lanes share THAT range, `per` consecutive bins each (1 or 2), instead of 8192 / kThreads bins of which all but
+  // a few dozen lanes' are empty.
+  const unsigned per = (bin_hi - bin_lo + (unsigned)kThreads) / (unsigned)kThreads;
+  const unsigned b0 = bin_lo + per * (unsigned)tid;
   unsigned my_nz = 0, my_cnt = 0;
   double my_sum = 0.0;
-#pragma unroll
-  for (int u = 0; u < kBinsPerThread; ++u) {
-    const unsigned b = (unsigned)kBinsPerThread * tid + u;
-    const unsigned long long h = hist1[b];
-    const unsigned c = (unsigned)(h >> 42);
-    my_nz += c ? 1u : 0u;
-    my_cnt += c;
-    my_sum += c ? bin_sum_exact(b << L1_SHIFT, c, h & kLowMask) : 0.0;
+#pragma unroll 2
+  for (unsigned u = 0; u < per; ++u) {
+    const unsigned b = b0 + u;
+    if (b <= bin_hi) {
+      const unsigned long long h = hist1[b];
+      const unsigned c = (unsigned)(h >> 42);
+      my_nz += c ? 1u : 0u;
+      my_cnt += c;
+      my_sum += c ? bin_sum_exact(b << L1_SHIFT, c, h & kLowMask) : 0.0;
+    }
   }
   unsigned enz = my_nz, ecnt = my_cnt, tnz, tcnt;
   double esum = my_sum, total;
@@ -204,23 +214,25 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
   unsigned flag_base = 0;                       // flagged bins in front of the current chunk
   for (unsigned chunk = 0; chunk < tnz; chunk += kNzCap) {
     if (chunk) __syncthreads();                 // the previous chunk's prefixes are done with
-    if (my_nz) {                                // (most lanes own empty bins only)
+    if (my_nz) {
       unsigned z = enz, c = ecnt;
       double sacc = esum;
-#pragma unroll 4
-      for (int u = 0; u < kBinsPerThread; ++u) {
-        const unsigned b = (unsigned)kBinsPerThread * tid + u;
-        const unsigned long long h = hist1[b];
-        const unsigned cn = (unsigned)(h >> 42);
-        if (cn) {
-          if (chunk == 0u) nzl[z] = (unsigned short)b;
-          if (z - chunk < (unsigned)kNzCap) {   // (unsigned wrap: entries in front of the chunk fail too)
-            lds->a.nz_r0[z - chunk] = c;
-            lds->a.nz_p0[z - chunk] = sacc;
+#pragma unroll 2
+      for (unsigned u = 0; u < per; ++u) {
+        const unsigned b = b0 + u;
+        if (b <= bin_hi) {
+          const unsigned long long h = hist1[b];
+          const unsigned cn = (unsigned)(h >> 42);
+          if (cn) {
+            if (chunk == 0u) nzl[z] = (unsigned short)b;
+            if (z - chunk < (unsigned)kNzCap) {   // (unsigned wrap: entries in front of the chunk fail too)
+              lds->a.nz_r0[z - chunk] = c;
+              lds->a.nz_p0[z - chunk] = sacc;
+            }
+            ++z;
+            c += cn;
+            sacc += bin_sum_exact(b << L1_SHIFT, cn, h & kLowMask);
           }
-          ++z;
-          c += cn;
-          sacc += bin_sum_exact(b << L1_SHIFT, cn, h & kLowMask);
         }
       }
     }
@@ -445,6 +457,20 @@ static __device__ __forceinline__ void scan_node(FusedLds* lds, unsigned n, unsi
   const int lane = threadIdx.x & 63;
   const double total = lds->total;
   const Node nd = lds->node[k];
+  if (depth > 0 && nd.kmin == nd.kmax) {
+    // more than 64 equal keys (the clamp value alpha, exact zeros, constants): one analytic run, no deeper rounds
+    const double v = (double)key_value(nd.kmin);
+    const unsigned sk = lds->cell[nd.cell];
+    const double succ_v = sk != kNoKey ? (double)key_value(sk) : INFINITY;
+    if (lane == 0 && run_has_candidate(v, nd.cnt, nd.r0, nd.p0, succ_v, n, total, ternary)) {
+      Best cb;
+      cb.cost = cost_of(v, nd.r0, nd.p0, nd.cnt, n, total, ternary);
+      cb.order = nd.r0;
+      cb.value = key_value(nd.kmin);
+      if (better(cb, best)) best = cb;
+    }
+    return;
+  }
   const int sh = 12 - 6 * depth;                       // key bits below the child index
   const unsigned long long hv = lds->b.nhist[k - cur_lo][lane];
   const unsigned c = (unsigned)(hv >> 42);
@@ -494,6 +520,24 @@ static __device__ __forceinline__ void scan_node(FusedLds* lds, unsigned n, unsi
     }
     return;
   }
+  {
+    // The clamp value alpha is usually the row's largest key and comes in hundreds to thousands of copies.  A
+    // child that holds the largest key holds nothing above it, so its low-bit sum equals c * low(maxkey) exactly
+    // when all its keys ARE the largest key: one analytic run instead of two more rounds over those keys.
+    const unsigned mx = lds->maxkey;
+    if (c > (unsigned)kWave && (mx >> sh) == (hi_key >> sh) &&
+        (hv & kLowMask) == (unsigned long long)c * (unsigned long long)(mx & lowmask)) {
+      const double v = (double)key_value(mx);
+      if (run_has_candidate(v, c, r0, p0, INFINITY, n, total, ternary)) {
+        Best cb;
+        cb.cost = cost_of(v, r0, p0, c, n, total, ternary);
+        cb.order = r0;
+        cb.value = key_value(mx);
+        if (better(cb, best)) best = cb;
+      }
+      return;
+    }
+  }
   // (a record whose table slot exists but whose resources ran out is written dead -- no keys, no table entry --
   // because the round bookkeeping counts it; its level-1 bin goes to the block path)
   const unsigned cid = atomicAdd(&lds->n_cells, 1u);
@@ -527,6 +571,8 @@ static __device__ __forceinline__ void scan_node(FusedLds* lds, unsigned n, unsi
       ch.p0 = p0;
       ch.root = nd.root;
       ch.pad = 0;
+      ch.kmin = kNoKey;
+      ch.kmax = 0u;
       lds->node[q] = ch;
       if (ok) store_lo16(&lds->b.centry[k][lane], q + 1u);
     }
@@ -610,6 +656,8 @@ static __device__ __forceinline__ void walk_key(FusedLds* lds, unsigned key, uns
     const unsigned c = (key >> sh) & 63u;
     if (d + 1 == round) {
       atomicAdd(&lds->b.nhist[k - cur_lo][c], kOne | (unsigned long long)(key & ((1u << sh) - 1u)));
+      atomicMin(&lds->node[k].kmin, key);
+      atomicMax(&lds->node[k].kmax, key);
       return;
     }
     ce = lds->b.centry[k][c];
@@ -625,7 +673,7 @@ template <int NK>
 static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n, unsigned tflag, bool ternary, Best best,
                                                 const unsigned (&kreg)[NK]) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int i = tid; i < L1_BINS / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->b.role)[i] = 0u;
+  for (int i = tid; i < L1_BINS / 2 + 1; i += kThreads) reinterpret_cast<unsigned*>(lds->b.role)[i] = 0u;
   for (int i = tid; i < kNodeCap * 64; i += kThreads) (&lds->b.centry[0][0])[i] = 0u;
   for (unsigned i = tid; i < tflag * 64u; i += kThreads) (&lds->b.nhist[0][0])[i] = 0ull;
   if (tid == 0) {
@@ -658,6 +706,8 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
       nd.p0 = sl.p0;
       nd.root = (unsigned)lane;
       nd.pad = 0;
+      nd.kmin = kNoKey;
+      nd.kmax = 0u;
       lds->node[lane] = nd;
       lds->cell[lane] = kNoKey;
       if (incl <= ((lds->args.debug & 2) ? 2048u : (unsigned)kListCap)) {
@@ -669,37 +719,40 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
     }
   }
   __syncthreads();
-  // register sweep 1: which keys to keep
-  constexpr int NM = (NK + 31) / 32, G = 16;
-  unsigned keep[NM];
-#pragma unroll
-  for (int q = 0; q < NM; ++q) keep[q] = 0u;
-  unsigned cnt = 0;
+  // One sweep over the key registers, 16 at a time: table look-ups (independent loads), one ballot per key, ONE
+  // list allocation per wave and group, then every kept key goes to base + (kept lanes below it).  Padding keys
+  // (kNoKey) index the always-zero extra table entry.
+  constexpr int G = 16;
 #pragma unroll
   for (int g0 = 0; g0 < NK; g0 += G) {
     unsigned ent[G];
 #pragma unroll
     for (int g = 0; g < G; ++g)
-      if (g0 + g < NK) ent[g] = lds->b.role[(kreg[g0 + g] >> L1_SHIFT) & (L1_BINS - 1)];
+      if (g0 + g < NK) ent[g] = lds->b.role[min(kreg[g0 + g] >> L1_SHIFT, (unsigned)L1_BINS)];
+    unsigned long long bm[G];
+    unsigned tot = 0;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if (g0 + g < NK) {
-        const bool k = ent[g] != 0u && (int)kreg[g0 + g] >= 0;
-        keep[(g0 + g) / 32] |= (k ? 1u : 0u) << ((g0 + g) % 32);
-        cnt += k ? 1u : 0u;
+        bm[g] = __ballot(ent[g] != 0u);
+        tot += (unsigned)__popcll(bm[g]);
       }
     }
-  }
-  {
-    const unsigned incl = wave_incl_scan(cnt);
-    unsigned base = 0;
-    if (lane == 63) base = atomicAdd(&lds->n_list, incl);
-    base = (unsigned)__shfl((int)base, 63);
-    unsigned pos = base + incl - cnt;
-    // register sweep 2: copy
+    if (tot) {                                    // (wave-uniform)
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(&lds->n_list, tot);
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
-    for (int i = 0; i < NK; ++i)
-      if ((keep[i / 32] >> (i % 32)) & 1u) lds->b.klist[pos++] = kreg[i];
+      for (int g = 0; g < G; ++g) {
+        if (g0 + g < NK) {
+          if (ent[g] != 0u) {
+            const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(bm[g] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm[g], 0u));
+            lds->b.klist[base + below] = kreg[g0 + g];
+          }
+          base += (unsigned)__popcll(bm[g]);
+        }
+      }
+    }
   }
   __syncthreads();
   FMARK(5);
@@ -715,6 +768,8 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
     // histogram, keys of a successor bin into the cell minimum.  Later rounds: the (rare) non-zero depth-0 entries
     // are walked one by one.
     constexpr int LG = 8;
+    const unsigned top_key = lds->maxkey;
+    unsigned top_cnt = 0;
     for (unsigned i0 = tid; i0 < n_list; i0 += LG * kThreads) {
       unsigned kk[LG], ce[LG];
 #pragma unroll
@@ -727,7 +782,10 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
           if (i0 + (unsigned)g * kThreads < n_list) {
             const unsigned nd = ce[g] & 0xFFu, sc = ce[g] >> 8;
             if (sc) atomicMin(&lds->cell[sc - 1u], kk[g]);
-            if (nd) atomicAdd(&lds->b.nhist[nd - 1u][(kk[g] >> 12) & 63u], kOne | (unsigned long long)(kk[g] & 0xFFFu));
+            if (kk[g] == top_key)
+              ++top_cnt;                         // (thousands of copies of one key: counted here, added once)
+            else if (nd)
+              atomicAdd(&lds->b.nhist[nd - 1u][(kk[g] >> 12) & 63u], kOne | (unsigned long long)(kk[g] & 0xFFFu));
           }
         }
       } else {
@@ -736,10 +794,32 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
           const unsigned nd = ce[g] & 0xFFu;
           ce[g] = nd ? lds->b.centry[nd - 1u][(kk[g] >> 12) & 63u] : 0u;
         }
+        // (few keys have work left: each lane walks ITS hits one after the other -- as many steps as the busiest
+        // lane has hits -- instead of the wave stepping through all LG key slots)
+        unsigned nz = 0;
 #pragma unroll
-        for (int g = 0; g < LG; ++g)
-          if (ce[g] && i0 + (unsigned)g * kThreads < n_list) walk_key(lds, kk[g], ce[g], round, cur_lo);
+        for (int g = 0; g < LG; ++g) nz |= (ce[g] != 0u && i0 + (unsigned)g * kThreads < n_list ? 1u : 0u) << g;
+        while (__ballot(nz != 0u)) {
+          if (nz) {
+            const int g = __ffs((int)nz) - 1;
+            nz &= nz - 1u;
+            unsigned key = kk[0], c = ce[0];
+#pragma unroll
+            for (int q = 1; q < LG; ++q) {
+              key = g == q ? kk[q] : key;
+              c = g == q ? ce[q] : c;
+            }
+            walk_key(lds, key, c, round, cur_lo);
+          }
+        }
       }
+    }
+    if (round == 0) {
+      top_cnt = wave_sum(top_cnt);
+      const unsigned nd = (unsigned)lds->b.role[min(top_key >> L1_SHIFT, (unsigned)L1_BINS)] & 0xFFu;
+      if (lane == 0 && top_cnt && nd)
+        atomicAdd(&lds->b.nhist[nd - 1u][(top_key >> 12) & 63u],
+                  (unsigned long long)top_cnt * kOne + (unsigned long long)top_cnt * (unsigned long long)(top_key & 0xFFFu));
     }
     __syncthreads();
     if (round == 0) FMARK(6);
@@ -802,8 +882,10 @@ static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
 // Everything between the level-1 histogram and v1.  `each_key` as in refine_resident.
 template <int NK>
 static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned minkey,
-                                                 bool ternary, const unsigned (&kreg)[NK]) {
+                                                 unsigned maxkey, bool ternary, const unsigned (&kreg)[NK]) {
   const int tid = threadIdx.x;
+  const unsigned bin_lo = min(minkey >> L1_SHIFT, (unsigned)L1_BINS - 1u), bin_hi = min(maxkey >> L1_SHIFT, (unsigned)L1_BINS - 1u);
+  if (tid == 0) lds->maxkey = maxkey;
   Best best;
   best.cost = INFINITY;
   best.order = kNoKey;
@@ -811,7 +893,7 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
   // Usual case: <= kFastSlots flagged bins -> on-chip refinement, nothing left for the block path.  Many
   // crossing bins (hist1 stays intact): every flagged bin through the block path, kSlotCap at a time.  (The
   // block path sits behind the last use of the resident keys, so they are not live across it.)
-  unsigned tflag = l1_scan(lds, n, 0u, ternary);
+  unsigned tflag = l1_scan(lds, n, 0u, ternary, bin_lo, bin_hi);
   FMARK(4);
   unsigned nslot, round0 = 0;
   bool listed = false;
@@ -826,16 +908,14 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
   } else {
     nslot = min((unsigned)kSlotCap, tflag);
   }
-#ifndef EXP_NO_SLOW
   while (nslot) {
     for (unsigned q = 0; q < nslot; ++q)
       best = resolve_slot_block(lds, xrow, n, listed ? (unsigned)lds->slow[q] : q, ternary, best);
     round0 += kSlotCap;
     if (round0 >= tflag) break;
-    l1_scan(lds, n, round0, ternary);
+    l1_scan(lds, n, round0, ternary, bin_lo, bin_hi);
     nslot = min((unsigned)kSlotCap, tflag - round0);
   }
-#endif
   // ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
   if (ternary && n > 0u && tid == 0) {
     const double mean = lds->total / (double)n;
@@ -852,14 +932,21 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
   return lds->v1;
 }
 
-static __device__ __forceinline__ unsigned block_min(unsigned v, FusedLds* lds) {
-  v = wave_min(v);
+static __device__ __forceinline__ void block_minmax(unsigned& mn, unsigned& mx, FusedLds* lds) {
+  mn = wave_min(mn);
+  mx = ~wave_min(~mx);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds->wa[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) {
+    lds->wa[threadIdx.x >> 6] = mn;
+    lds->wb[threadIdx.x >> 6] = mx;
+  }
   __syncthreads();
-  unsigned m = kNoKey;
-  for (int w = 0; w < kWaves; ++w) m = min(m, lds->wa[w]);
-  return m;
+  mn = kNoKey;
+  mx = 0u;
+  for (int w = 0; w < kWaves; ++w) {
+    mn = min(mn, lds->wa[w]);
+    mx = max(mx, lds->wb[w]);
+  }
 }
 
 static __device__ __forceinline__ void hist_add(FusedLds* lds, unsigned key) {
@@ -1074,8 +1161,9 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   const int HW = a.H * a.W;
   const long long M = a.row_elems;
   const bool affine = a.pre_scale != nullptr;
+  const bool bn_lds = a.C <= kBnCap;
   unsigned kreg[4 * U];
-  unsigned mk = kNoKey;
+  unsigned mk = kNoKey, xk = 0u;
   {
     const float4* __restrict__ row4 = reinterpret_cast<const float4*>(xrow);
     const unsigned nvec = (unsigned)(M / 4);
@@ -1100,21 +1188,38 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
           const unsigned e0 = 12u * jt;
           float xs[4] = {v[b][0].x, v[b][0].w, v[b][1].z, v[b][2].y};
           if (affine) {
-            // channel of element e0 (e0 / HW via a reciprocal, corrected); the other three are at most one
-            // channel boundary further each (HW >= 4)
+            // channel of element e0 (e0 / HW via a reciprocal, corrected); the other three sub-sampled elements
+            // are at most one channel boundary further each (HW >= 4).  Scale / shift come from the LDS copy.
             const unsigned ec = min(e0, (unsigned)(M - 1));
             unsigned c = (unsigned)((float)ec * hinv);
             if ((c + 1u) * (unsigned)HW <= ec) ++c;
             if (c * (unsigned)HW > ec) --c;
             unsigned r = ec - c * (unsigned)HW;        // position inside the channel
+            auto bn = [&](unsigned ch, float& sc, float& sh) {      // (uniform branch: LDS copy or global)
+              if (bn_lds) {
+                sc = lds->bn_s[ch];
+                sh = lds->bn_t[ch];
+              } else {
+                sc = a.pre_scale[ch];
+                sh = a.pre_shift[ch];
+              }
+            };
+            if (r + 9u < (unsigned)HW) {               // the usual case: all four in one channel
+              float sc, sh;
+              bn(c, sc, sh);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const unsigned ce = min(c, (unsigned)a.C - 1u);
-              xs[e] = fmaf(xs[e], a.pre_scale[ce], a.pre_shift[ce]);
-              r += 3u;
-              if (r >= (unsigned)HW) {
-                r -= (unsigned)HW;
-                ++c;
+              for (int e = 0; e < 4; ++e) xs[e] = fmaf(xs[e], sc, sh);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float sc, sh;
+                bn(min(c, (unsigned)a.C - 1u), sc, sh);
+                xs[e] = fmaf(xs[e], sc, sh);
+                r += 3u;
+                if (r >= (unsigned)HW) {
+                  r -= (unsigned)HW;
+                  ++c;
+                }
               }
             }
           }
@@ -1125,6 +1230,7 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
             if (has) {
               hist_add(lds, key);
               mk = min(mk, key);
+              xk = max(xk, key);
             }
             kreg[4 * (u0 + b) + e] = has ? key : kNoKey;
           }
@@ -1132,11 +1238,12 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
       }
     }
   }
-  const unsigned minkey = block_min(mk, lds);      // (its barriers also close the histogram)
+  unsigned minkey = mk, maxkey = xk;
+  block_minmax(minkey, maxkey, lds);               // (its barriers also close the histogram)
   FMARK(1);
   const unsigned n = (unsigned)((M + 2) / 3);
   const bool ternary = a.ternary != 0;
-  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, ternary, kreg);
+  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, maxkey, ternary, kreg);
 
   FMARK(9);
   // pass 2: both planes and sum |x - v1 b1|
@@ -1185,11 +1292,6 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
   else if (HW % 2 == 0 && (long long)a.Gt * (HW / 2) >= T) vec = 2;
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
-#ifdef EXP_T1024
-  if (need <= 2) return launch<1024, 3>(a, vec, st);
-  if (need <= 4) return launch<1024, 5>(a, vec, st);
-  if (need <= 8) return launch<1024, 9>(a, vec, st);
-#endif
   if (need <= 5) return launch<T, 5>(a, vec, st);
   if (need <= 9) return launch<T, 9>(a, vec, st);
   if (need <= 17) return launch<T, 17>(a, vec, st);

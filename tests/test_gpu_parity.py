@@ -250,6 +250,69 @@ def test_solver_rare_paths_are_exercised():
     assert np.array_equal(v, E.solve_rows(big, False, 1))
 
 
+def _fused_cases():
+    """Hard rows in activation shapes that take the single-launch quantizer (lsq_act_fused.hip)."""
+    rs = np.random.RandomState(11)
+
+    def relu_affine(n, c, hw):
+        return (np.maximum(rs.standard_normal((n, c, hw)), 0) * (0.5 + rs.random_sample((1, c, 1))) * 1.7
+                + rs.standard_normal((1, c, 1)) * 0.5 - 0.7)
+    return {
+        'gauss56': (rs.standard_normal((3, 64, 56, 56)) * 1.3, 3.0),              # keys resident: 132 registers per lane
+        'saturated28': (rs.standard_normal((3, 128, 28, 28)) * 4.0, 2.0),         # thousands of copies of the clamp value
+        'relu14': (np.maximum(rs.standard_normal((4, 256, 14, 14)), 0), 3.0),     # half the keys are exact zeros
+        'relu_affine28': (relu_affine(3, 128, 784).reshape(3, 128, 28, 28), 3.0),  # 128 constants of high multiplicity
+        'ties7': (np.round(rs.standard_normal((4, 512, 7, 7)) * 4) / 4, -1.0),    # a handful of distinct keys, no clamp
+        'const': (np.full((2, 64, 12, 12), -1.75), 3.0),
+        'two_values': (np.where(rs.random_sample((3, 64, 16, 16)) < 0.5, 0.25, -1.0), 3.0),
+        'narrow': (1.0 + 1e-4 * rs.standard_normal((2, 128, 14, 14)), 3.0),       # dense children: three rounds
+        'wide': (np.exp(rs.standard_normal((2, 64, 20, 20)) * 8) * np.sign(rs.standard_normal((2, 64, 20, 20))), -1.0),
+        'loguniform': (np.exp(rs.random_sample((2, 64, 28, 28)) * 40 - 20), -1.0),  # > 40 crossing bins: block path
+        'lenet': (rs.standard_normal((5, 20, 12, 12)), 2.0),                      # 20 channels: generic pass 2
+        'odd_hw': (rs.standard_normal((3, 192, 7, 7)) * 2, 2.0),                  # H*W not a multiple of 4
+    }
+
+
+@pytest.mark.parametrize('ternary', [False, True])
+def test_fused_quantizer_equals_exact_oracle_and_streaming_path(ternary):
+    """The single-launch quantizer against oracle/lsq_exact.py (v1 bit-equal), the plane chain, and the streaming
+    three-kernel path (everything bit-equal), with its rare paths forced as well: mode 1 = every flagged bin
+    through the block path, mode 2 = a 2048-key list (most bins overflow)."""
+    import ctypes
+    hip = _hip()
+    lib = hip.lib()
+    lib.lsq_debug_force_streaming.argtypes = [ctypes.c_int]
+    lib.lsq_debug_fused_mode.argtypes = [ctypes.c_int]
+    scheme = 3 if ternary else 2
+    for tag, (arr, alpha) in _fused_cases().items():
+        x = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+        n = x.shape[0]
+        pad = (0, 0) if tag == 'lenet' else (1, 1)
+        xc = x if alpha < 0 else x.clamp(-alpha, alpha)
+        exact = E.solve_rows(xc.reshape(n, -1).numpy(), ternary, 3)
+        results = {}
+        try:
+            for name, force, mode in (('fused', 0, 0), ('block', 0, 1), ('small-list', 0, 2), ('streaming', 1, 0)):
+                lib.lsq_debug_force_streaming(force)
+                lib.lsq_debug_fused_mode(mode)
+                results[name] = run_act_quant(x, scheme, 2, alpha, 1, pad)
+        finally:
+            lib.lsq_debug_force_streaming(0)
+            lib.lsq_debug_fused_mode(0)
+        planes, scales = results['fused']
+        assert np.array_equal(scales[0].numpy(), exact), (tag, scales[0], exact)
+        for q, b in enumerate(planes_ref(xc, [scales[0], scales[1]])):
+            assert np.array_equal(planes[q], pack_ref(b, 1, pad)), (tag, q)
+        if not ternary:
+            v2 = P.quant_ls2(xc, scales[0])[1]
+            assert torch.allclose(scales[1], v2, rtol=2e-6, atol=1e-12), tag
+        for name in ('block', 'small-list', 'streaming'):
+            p2, s2 = results[name]
+            assert np.array_equal(s2[0].numpy(), scales[0].numpy()), (tag, name)
+            assert torch.allclose(s2[1], scales[1], rtol=3e-7, atol=0), (tag, name)     # fp64 sums in another order
+            assert np.array_equal(p2[0], planes[0]) and np.array_equal(p2[1], planes[1]), (tag, name)
+
+
 @pytest.mark.parametrize('skip', [1, 2, 5])
 def test_act_quant_other_skips_and_tiny_shapes(skip):
     """Sub-sampling strides other than the reference's default and degenerate geometries."""
