@@ -20,6 +20,8 @@ _lib = None
 ABI_VERSION = 3
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
+MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
+MAX_SOLVER_KEYS = 1 << 22    # lsq_act_quant LS-2 / LS-T: sub-sampled keys per row
 
 
 class ConvGeom(ctypes.Structure):
@@ -95,8 +97,15 @@ def check(code: int, what: str) -> None:
         raise LsqHipError(f'{what} failed with code {code}: {msg}')
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """HIP stream the kernels of ``device`` are launched on (torch's current stream of THAT device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _on(t: torch.Tensor):
+    """Device guard for a C-ABI call: the library never calls hipSetDevice, so the tensor's device is made
+    current around the launch (a model on cuda:1 with cuda:0 current must not launch on cuda:0's stream)."""
+    return torch.cuda.device(t.device)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -145,7 +154,7 @@ class _Timed:
 
     def __enter__(self):
         self.on = _timing is not None and (_timing_only is None or self.name in _timing_only)
-        if self.on:
+        if self.on:                       # (events record on the current stream of the current device: call inside _on)
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
             self.s.record()
@@ -163,7 +172,10 @@ def solver_workspace(rows: int, device) -> torch.Tensor:
     """Scratch for the LS2/LST solve (slot records passed from the sweep to the solve kernel); cached per
     device and grown on demand -- kernels of one stream run in order, so sharing it is safe."""
     need = lib().lsq_solver_workspace_bytes(rows)
-    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty((need,), dtype=torch.uint8, device=device)
@@ -178,11 +190,11 @@ def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, a
     x = _f32c(x)
     ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) and forced is None else None
     m = geom.C * geom.H * geom.W
-    with _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8)):     # x read once + k bit planes written
+    with _on(x), _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8)):     # x read once + k bit planes written
         check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha),
                                   None if pre is None else pre[0].data_ptr(), None if pre is None else pre[1].data_ptr(),
                                   ptr(forced), planes.data_ptr(), scales.data_ptr(), ptr(ws),
-                                  0 if ws is None else ws.numel(), stream_ptr()), 'lsq_act_quant')
+                                  0 if ws is None else ws.numel(), stream_ptr(x.device)), 'lsq_act_quant')
 
 
 def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0):
@@ -192,8 +204,9 @@ def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0
     v12 = torch.empty((2, r), dtype=torch.float32, device=rows.device)
     status = torch.empty((r,), dtype=torch.int32, device=rows.device)
     ws = solver_workspace(r, rows.device)
-    check(lib().lsq_solve_rows(rows.data_ptr(), r, m, skip, int(ternary), float(alpha), v12.data_ptr(),
-                               status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()), 'lsq_solve_rows')
+    with _on(rows):
+        check(lib().lsq_solve_rows(rows.data_ptr(), r, m, skip, int(ternary), float(alpha), v12.data_ptr(),
+                                   status.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(rows.device)), 'lsq_solve_rows')
     return v12, status
 
 
@@ -205,8 +218,9 @@ def pack_weight(w: torch.Tensor, geom: ConvGeom, scales: torch.Tensor):
     words = lib().lsq_weight_plane_words(ctypes.byref(geom))
     wbits = torch.empty((k * words,), dtype=torch.int64, device=w.device)
     wsum = torch.empty((k, geom.O, geom.KH * geom.KW), dtype=torch.int32, device=w.device)
-    check(lib().lsq_pack_weight(w.data_ptr(), ctypes.byref(geom), k, scales.data_ptr(), wbits.data_ptr(),
-                                wsum.data_ptr(), stream_ptr()), 'lsq_pack_weight')
+    with _on(w):
+        check(lib().lsq_pack_weight(w.data_ptr(), ctypes.byref(geom), k, scales.data_ptr(), wbits.data_ptr(),
+                                    wsum.data_ptr(), stream_ptr(w.device)), 'lsq_pack_weight')
     return wbits, wsum
 
 
@@ -227,10 +241,10 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
     """y = relu?(conv + bias + res_pre) + res_post (the fused block epilogue is optional)."""
     m = geom.C * geom.H * geom.W
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
-    with _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs):   # planes read + fp32 output written
+    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs):   # planes read + fp32 output written
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu),
-                                    ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr()), 'lsq_xnor_conv2d')
+                                    ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
 
 
 def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,
@@ -239,11 +253,11 @@ def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: to
                  res_post: Optional[torch.Tensor] = None) -> None:
     x = _f32c(x)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
-    with _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel(), flops):     # fp32 input read + fp32 output written
+    with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel(), flops):     # fp32 input read + fp32 output written
         check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), None if pre is None else pre[0].data_ptr(),
                                      None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wscales.shape[0],
                                      wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu), ptr(res_pre),
-                                     ptr(res_post), y.data_ptr(), stream_ptr()), 'lsq_signw_conv2d')
+                                     ptr(res_post), y.data_ptr(), stream_ptr(x.device)), 'lsq_signw_conv2d')
 
 
 def pool_bias_relu_nhwc(x: torch.Tensor, kernel: int, stride: int, pad: int, bias: Optional[torch.Tensor],
@@ -255,8 +269,8 @@ def pool_bias_relu_nhwc(x: torch.Tensor, kernel: int, stride: int, pad: int, bia
     n, c, h, w = x.shape
     ho, wo = (h + 2 * pad - kernel) // stride + 1, (w + 2 * pad - kernel) // stride + 1
     y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
-    with _Timed('lsq_pool_bias_relu_nhwc', 4 * x.numel() + 4 * y.numel(), 0):
+    with _on(x), _Timed('lsq_pool_bias_relu_nhwc', 4 * x.numel() + 4 * y.numel(), 0):
         check(lib().lsq_pool_bias_relu_nhwc(x.data_ptr(), n, c, h, w, kernel, stride, pad,
                                             ptr(None if bias is None else _f32c(bias)), int(relu), y.data_ptr(),
-                                            stream_ptr()), 'lsq_pool_bias_relu_nhwc')
+                                            stream_ptr(x.device)), 'lsq_pool_bias_relu_nhwc')
     return y

@@ -115,7 +115,30 @@ class QuantConv2d(nn.Conv2d):
             return False
         if self.w_quant == 'fp':          # nothing binary on the weight side: plain conv
             return False
+        return self._hip_supports(x)
+
+    def _hip_supports(self, x: torch.Tensor) -> bool:
+        """The limits of the kernels (include/lsq_hip.h); anything outside them takes the torch formulation,
+        exactly as training and CPU tensors do: fp32 only, at most 8 bit planes, kernels up to 8x8 on the
+        XNOR path, at most 2^22 sub-sampled keys per row for the LS-2 / LS-T solve."""
+        from quant import _hip
+        if x.dtype != torch.float32 or self.weight.dtype != torch.float32:
+            return False
+        if getattr(self.w_approximate, 'k', 1) > _hip.MAX_PLANES:      # gf-k weights: k planes
+            return False
+        if self.x_quant != 'fp':
+            if getattr(self.x_approximate, 'n_planes', 1) > _hip.MAX_PLANES or max(self.kernel_size) > _hip.MAX_XNOR_KERNEL:
+                return False
+            if self.x_quant in ('ls-2', 'ls-T'):
+                m = x.shape[1] * x.shape[2] * x.shape[3]
+                if (m + self.act_skip - 1) // self.act_skip >= _hip.MAX_SOLVER_KEYS:
+                    return False
         return True
+
+    def _replicate_for_data_parallel(self):
+        replica = super()._replicate_for_data_parallel()
+        replica._hip_cache = {}           # packed weights / workspaces live on the replica's own device
+        return replica
 
     def train(self, mode: bool = True):
         if mode:
@@ -198,7 +221,9 @@ class QuantConv2d(nn.Conv2d):
             return y
         xq = self.x_approximate
         k = xq.n_planes
-        key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device)
+        # (one workspace per launch stream: two streams through one module must not share planes and scales)
+        key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device,
+               torch.cuda.current_stream(x.device).cuda_stream)
         ws = self._hip_cache.get(key)
         if ws is None:
             words = _hip.act_plane_words(geom)
@@ -206,9 +231,9 @@ class QuantConv2d(nn.Conv2d):
             ws = (torch.zeros((k * words,), dtype=torch.int64, device=x.device),
                   torch.empty((k, n), dtype=torch.float32, device=x.device))
             # one plane workspace per input shape; serving with many batch sizes must not grow without bound
-            stale = [kk for kk in self._hip_cache if isinstance(kk, tuple) and kk[0] == 'act']
+            stale = [kk for kk in list(self._hip_cache) if isinstance(kk, tuple) and kk[0] == 'act']
             for kk in stale[:max(0, len(stale) - 3)]:
-                del self._hip_cache[kk]
+                self._hip_cache.pop(kk, None)
             self._hip_cache[key] = ws
         planes, scales = ws
         forced = xq.eval_scales(n)

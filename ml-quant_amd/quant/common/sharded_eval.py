@@ -21,23 +21,53 @@ def local_slice(n: int, rank: int, world: int) -> slice:
     return slice(start, start + base + (1 if rank < extra else 0))
 
 
-def all_gather_logits(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None) -> torch.Tensor:
-    """Concatenate every rank's ``[B_local, classes]`` logits along dim 0 (equal B_local on all ranks)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def all_gather_logits(local: torch.Tensor, out: Optional[torch.Tensor] = None, group=None,
+                      total: Optional[int] = None, always_collective: bool = False) -> torch.Tensor:
+    """Concatenate every rank's ``[B_local, classes]`` logits along dim 0.
+
+    ``total`` = the number of samples over all ranks when they were split with :func:`local_slice`; it may be
+    omitted when every rank holds the same number.  Collectives need identical shapes on every rank, so uneven
+    shards are padded to the largest one for the exchange and trimmed afterwards.  ``always_collective`` issues the
+    collective with a single rank too (the one-GPU check that the RCCL path works end to end)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    if dist.get_world_size(group) == 1 and not always_collective:
         return local
     world = dist.get_world_size(group)
-    if out is None:
-        out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
-    local = local.contiguous()
+    sizes = None
+    if total is not None:
+        sizes = [local_slice(total, r, world) for r in range(world)]
+        sizes = [s.stop - s.start for s in sizes]
+        if sizes[dist.get_rank(group)] != local.shape[0]:
+            raise ValueError(f'rank holds {local.shape[0]} samples, local_slice({total}, ...) gives {sizes[dist.get_rank(group)]}')
+        if len(set(sizes)) == 1:
+            sizes = None
+    if sizes is None:
+        if out is None:
+            out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
+        local = local.contiguous()
+        if local.is_cuda:
+            dist.all_gather_into_tensor(out, local, group=group)
+        else:
+            dist.all_gather(list(out.chunk(world, dim=0)), local, group=group)
+        return out
+    widest = max(sizes)
+    padded = local.new_zeros((widest,) + tuple(local.shape[1:]))
+    padded[:local.shape[0]] = local
+    buf = local.new_empty((world * widest,) + tuple(local.shape[1:]))
     if local.is_cuda:
-        dist.all_gather_into_tensor(out, local, group=group)
+        dist.all_gather_into_tensor(buf, padded, group=group)
     else:
-        dist.all_gather(list(out.chunk(world, dim=0)), local, group=group)
+        dist.all_gather(list(buf.chunk(world, dim=0)), padded, group=group)
+    parts = [buf[r * widest:r * widest + sizes[r]] for r in range(world)]
+    if out is None:
+        return torch.cat(parts, dim=0)
+    torch.cat(parts, dim=0, out=out)
     return out
 
 
 @torch.no_grad()
 def evaluate_sharded(model: torch.nn.Module, x_local: torch.Tensor, out: Optional[torch.Tensor] = None,
-                     group=None) -> torch.Tensor:
+                     group=None, total: Optional[int] = None, always_collective: bool = False) -> torch.Tensor:
     """One inference step: local forward on this rank's shard, then the all-gather of logits."""
-    return all_gather_logits(model(x_local), out, group)
+    return all_gather_logits(model(x_local), out, group, total, always_collective)

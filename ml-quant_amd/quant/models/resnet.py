@@ -78,7 +78,8 @@ class _Stem(nn.Sequential):
             y = nn.functional.conv2d(x.contiguous(memory_format=torch.channels_last), hit[1], None,
                                      conv.stride, conv.padding, conv.dilation, conv.groups)
             geom = _square_pool(pool)
-            if geom is not None and isinstance(relu, nn.ReLU) and y.is_contiguous(memory_format=torch.channels_last):
+            if (geom is not None and isinstance(relu, nn.ReLU) and y.dtype == torch.float32
+                    and y.is_contiguous(memory_format=torch.channels_last)):
                 # pool + bias + ReLU + NHWC -> NCHW in one HBM pass (csrc/lsq_pool.hip)
                 return _hip.pool_bias_relu_nhwc(y, *geom, b, True)
             y = pool(y)

@@ -40,6 +40,67 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _tiny_resnet():
+    """A QResNet small enough for the CPU suite with the real block structure (xnor blocks, double shortcut,
+    a stride-2 stage with its projection shortcut), ls-1 weights / ls-2 activations as the headline config."""
+    import detgen
+    from quant.binary.binary_conv import QuantConv2d
+    from quant.models.resnet import QResNet
+
+    def layer(alpha):
+        return {'x_quant': 'ls-2', 'w_quant': 'ls-1', 'clamp': {'kind': 'symmetric', 'alpha': alpha}, 'double_shortcut': True}
+    arch = {'moving_average_mode': 'off', 'moving_average_momentum': 0.99, 'block': 'xnor',
+            'layer0': {'n_in_channels': 16, 'kernel_size': 3, 'stride': 1, 'padding': 1, 'bias': False,
+                       'maxpool': {'type': 'identity'}},
+            'layer1': layer(3), 'layer2': layer(3), 'layer3': layer(3), 'layer4': layer(3),
+            'nonlins': ['relu', 'relu'], 'num_blocks': [1, 1, 1, 1], 'output_classes': 10}
+    model = QResNet(loss_fn=None, **arch)
+    detgen.fill_module(model, seed=9)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, QuantConv2d):
+                m.w_approximate.v1.copy_(m.weight.abs().mean(dim=(1, 2, 3)))
+    return model.eval()
+
+
+def _worker_resnet_uneven(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'ml-quant_amd'), os.path.join(ROOT, 'tests', 'golden')):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import detgen
+    from quant.common.sharded_eval import evaluate_sharded, local_slice
+    torch.set_num_threads(2)
+    model = _tiny_resnet()
+    n = 7                                            # 4 + 3: shards of different size
+    x = detgen.normal('dist.rx', (n, 3, 16, 16))
+    gathered = evaluate_sharded(model, x[local_slice(n, rank, world)], total=n)
+    out = torch.empty((n, 10))
+    evaluate_sharded(model, x[local_slice(n, rank, world)], out=out, total=n)
+    with torch.no_grad():
+        full = model(x)
+        local = model(x[local_slice(n, rank, world)])
+    torch.save({'gathered': gathered, 'out': out, 'full': full, 'local': local}, os.path.join(out_dir, f'q{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_resnet_uneven_shards_world2_gloo(tmp_path):
+    """A QResNet (not only LeNet) through evaluate_sharded with world size 2 and a batch that does not divide
+    evenly: shards are padded for the collective and trimmed afterwards."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_resnet_uneven, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ds = [torch.load(os.path.join(str(tmp_path), f'q{r}.pt')) for r in range(world)]
+    shards = torch.cat([d['local'] for d in ds], dim=0)
+    for d in ds:
+        assert d['gathered'].shape == (7, 10)
+        # the exchange itself is exact; the fp32 stem / classifier of torch-CPU are not bitwise batch-size invariant,
+        # so the comparison with the unsharded forward carries a rounding tolerance
+        assert torch.equal(d['gathered'], shards) and torch.equal(d['out'], shards)
+        assert torch.allclose(d['gathered'], d['full'], rtol=1e-5, atol=1e-5)
+
+
 def test_sharded_eval_world2_gloo(tmp_path):
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)

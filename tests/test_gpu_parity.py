@@ -813,3 +813,34 @@ def test_random_conv_geometries_against_oracle():
             geo = (xs, (n, cin, h, w), cout, (kh, kw), stride, pad, dil, groups)
             assert y.shape == ref.shape, geo
             assert rel_err(y, ref) <= TOL, (geo, rel_err(y, ref))
+
+
+def test_sharded_eval_over_rccl_with_one_rank():
+    """The multi-GPU inference step on the one GPU there is: an nccl (= RCCL) process group of world size 1, the
+    ResNet-18 headline config on the HIP path through evaluate_sharded with the collective forced -> the plain
+    forward, bit for bit.  (N > 1 is covered by the gloo world-size-2 tests on CPU and measured by the driver.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    import bench
+    from quant.common.sharded_eval import evaluate_sharded
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        model = bench.build_model(bench.imagenet_arch(), torch.device(DEV))
+        x = detgen.normal('gpu.rccl.x', (8, 3, 224, 224)).to(DEV)
+        with torch.no_grad():
+            plain = model(x)
+        out = torch.empty_like(plain)
+        gathered = evaluate_sharded(model, x, out=out, total=8, always_collective=True)
+        torch.cuda.synchronize()
+        assert gathered.data_ptr() == out.data_ptr() and torch.equal(gathered, plain)
+    finally:
+        if created:
+            dist.destroy_process_group()
