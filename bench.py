@@ -82,31 +82,128 @@ def pmc_traffic_per_launch(entry):
     return {'bytes_per_launch': total / calls, 'source': os.path.basename(tables[-1])} if launches else None
 
 
+def cifar_arch():
+    """arch_config of examples/cifar100/cifar100_ls1_kd.yaml (model section): 18-layer XNOR ResNet, 3x3 stem, no
+    max-pool, ls-1 weights AND activations, clamp alpha = 2."""
+    a = imagenet_arch('ls-1', 2)
+    a['layer0'] = {'n_in_channels': 64, 'kernel_size': 3, 'stride': 1, 'padding': 1, 'bias': False,
+                   'maxpool': {'type': 'identity'}}
+    a['output_classes'] = 100
+    return a
+
+
+def build_lenet(device):
+    """examples/mnist/mnist_ls1_weight_fp_activation.yaml (BASELINE.json configs[0]): ls-1 weights, fp activations."""
+    from quant.models.lenet import QLeNet5
+    torch.manual_seed(0)
+    model = QLeNet5(loss_fn=torch.nn.functional.nll_loss, x_quant='fp', w_quant='ls-1', clamp={'kind': 'identity'},
+                    conv1_filters=20, conv2_filters=50, output_classes=10)
+    with torch.no_grad():
+        model.conv2.w_approximate.v1.copy_(model.conv2.weight.abs().mean(dim=(1, 2, 3)))
+    return model.eval().to(device)
+
+
+POPCOUNT_PEAK_T = 1258.0      # SURVEY 8(d): 256 CU x 128 lanes x 2.4 GHz, v_xor + v_bcnt per 32 binary MACs
+HBM_PEAK_GBPS = 8000.0
+MFMA_BF16_PEAK_T = 2500.0
+PATH_ROOFLINE_IMG_S = {'ls-2': 628e3, 'ls-T': 628e3, 'ls-1': 628e3, 'gf-2': 628e3, 'fp': 628e3}   # 8 TB/s / 12.74 MB (SURVEY 8(d))
+
+
+def kernel_roofline(name, launches, ms, nbytes, ops):
+    """The roofline entry of one path kernel: the bound SURVEY 8(d) assigns to it (quantizer: HBM; XNOR conv:
+    VALU popcount with HBM second; sign-weight conv: bf16 MFMA with both passes counted)."""
+    sec = ms * 1e-3
+    hbm = {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+           'frac': nbytes / sec / 1e9 / HBM_PEAK_GBPS}
+    if name == 'lsq_xnor_conv2d':
+        t = ops / sec / 1e12
+        r = {'bound': 'valu-popcount', 'achieved': t, 'peak': POPCOUNT_PEAK_T, 'unit': 'T binary-MAC/s',
+             'frac': t / POPCOUNT_PEAK_T, 'secondary': hbm}
+    elif name == 'lsq_signw_conv2d':
+        t = ops / sec / 1e12
+        r = {'bound': 'mfma', 'achieved': t, 'peak': MFMA_BF16_PEAK_T, 'unit': 'TFLOP/s', 'frac': t / MFMA_BF16_PEAK_T,
+             'note': 'bf16 hi + lo passes both counted (useful fraction = half)', 'secondary': hbm}
+    else:
+        r = hbm
+    r.update(kernel=name, launches=launches, avg_launch_us=1e3 * ms / max(launches, 1))
+    return r
+
+
+def timed_forward(fn, steps, warmup, chunks=10):
+    """(images-independent) wall seconds for `steps` calls of fn bracketed by synchronize, plus the per-step
+    minimum / median over `chunks` event-bracketed groups of steps (events only between groups)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    per = max(1, steps // chunks)
+    groups = [per] * (steps // per) + ([steps % per] if steps % per else [])
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i, n in enumerate(groups):
+        for _ in range(n):
+            fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = sorted(evs[i].elapsed_time(evs[i + 1]) / n for i, n in enumerate(groups))
+    return elapsed, ms[0], ms[len(ms) // 2]
+
+
+def config_leg(tag, model, x, steps, warmup, workload, cpu_reference_img_s=None):
+    """One of the other single-GPU configs of BASELINE.json as a short leg of the same process."""
+    from quant import _hip
+    with torch.no_grad():
+        fn = lambda: model(x)      # noqa: E731
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        _hip.enable_timing(True)
+        fn()
+        torch.cuda.synchronize()
+        table = _hip.drain_timing()
+        _hip.enable_timing(False)
+        elapsed, ms_min, ms_med = timed_forward(fn, steps, 2)
+    path = {k: v for k, v in table.items() if k in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d')}
+    out = {'workload': workload, 'batch': x.shape[0], 'steps': steps, 'value': x.shape[0] * steps / elapsed, 'unit': 'images/sec',
+           'ms_per_step': 1e3 * elapsed / steps, 'ms_per_step_min': ms_min, 'ms_per_step_median': ms_med}
+    if path:
+        dom = max(path, key=lambda k: path[k][1])
+        out['roofline'] = kernel_roofline(dom, *path[dom])
+        out['roofline']['measured'] = 'HIP events around every C-ABI call of one instrumented step'
+        out['kernels_ms_per_step'] = {k: round(v[1], 4) for k, v in table.items()}
+    if cpu_reference_img_s is not None:
+        out['reference_cpu_images_per_sec_survey'] = cpu_reference_img_s
+    return out
+
+
 def cpu_baseline(arch, model, sample):
     """The oracle's whole-network forward (same algorithmic structure as the reference: sort + cumsum +
-    mask + [N,K,M] cost + fp32 conv) timed on this box's host cores on a bounded sample."""
+    mask + [N,K,M] cost + fp32 conv; scripts/cpu_oracle_vs_reference.py times the two side by side in the build
+    container) on this box's host cores, ONE batch of `sample` images as SURVEY 8(d) states (B = 64)."""
     from oracle import ref_models
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(0)
     x = torch.randn(sample, 3, 224, 224, generator=g)
     with torch.no_grad():
-        ref_models.resnet_forward(sd, arch, x[:2], chunk=16)           # warm-up (thread pools, allocator)
+        ref_models.resnet_forward(sd, arch, x[:2])                      # warm-up (thread pools, allocator)
         t0 = time.perf_counter()
-        ref_models.resnet_forward(sd, arch, x, chunk=16)
+        ref_models.resnet_forward(sd, arch, x)
         dt = time.perf_counter() - t0
     return {'value': sample / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{sample} images of the same workload, one forward ({dt:.1f} s), '
+            'sample': f'one eval forward of a batch of {sample} images of the same workload ({dt:.1f} s), '
                       f'host cpu_count={os.cpu_count()}'}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--cpu-sample', type=int, default=48, help='images for the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='batch of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the legs of the other single-GPU configs')
     ap.add_argument('--act', default='ls-2', choices=['ls-1', 'ls-2', 'ls-T', 'gf-2', 'fp'],
                     help='activation scheme (default: the headline ls-2 config)')
     args = ap.parse_args()
@@ -123,16 +220,17 @@ def main():
         dist.barrier()
 
     from quant import _hip
+    from quant.common.sharded_eval import all_gather_logits, evaluate_sharded
     arch = imagenet_arch(args.act, 3 if args.act == 'ls-2' else 2)
     model = build_model(arch, device)
     g = torch.Generator(device='cpu').manual_seed(rank)
     x = torch.randn(args.batch, 3, 224, 224, generator=g).to(device)       # resident in HBM before timing
-    gathered = torch.empty((world * args.batch, 1000), dtype=torch.float32, device=device) if world > 1 else None
-
-    from quant.common.sharded_eval import evaluate_sharded
+    gathered = torch.empty((world * args.batch, 1000), dtype=torch.float32, device=device) if dist.is_initialized() else None
+    under_torchrun = dist.is_initialized()
 
     def step():
-        return evaluate_sharded(model, x, gathered)       # local forward + RCCL all-gather of logits
+        # local forward + RCCL all-gather of logits (issued with one rank too when launched by torchrun)
+        return evaluate_sharded(model, x, gathered, always_collective=under_torchrun)
 
     for _ in range(args.warmup):
         step()
@@ -152,61 +250,117 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # EXACTLY args.steps timed steps between the synchronisation points; events between groups of steps (none
+    # inside a step) give the per-step minimum / median
+    per = max(1, args.steps // 10)
+    groups = [per] * (args.steps // per) + ([args.steps % per] if args.steps % per else [])
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    evs[0].record()
+    for i, n in enumerate(groups):
+        for _ in range(n):
+            step()
+        evs[i + 1].record()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    group_ms = sorted(evs[i].elapsed_time(evs[i + 1]) / n for i, n in enumerate(groups))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    timed_table = _hip.drain_timing() if not args.no_roofline else {}
+    _hip.enable_timing(False)
+
+    allgather = None
+    if under_torchrun:
+        # the exchange step alone: [batch, 1000] fp32 logits per rank, events on the launch stream
+        logits = torch.randn(args.batch, 1000, device=device)
+        for _ in range(5):
+            all_gather_logits(logits, gathered, always_collective=True)
+        torch.cuda.synchronize()
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        s_ev.record()
+        for _ in range(reps):
+            all_gather_logits(logits, gathered, always_collective=True)
+        e_ev.record()
+        torch.cuda.synchronize()
+        us = 1e3 * s_ev.elapsed_time(e_ev) / reps
+        t = torch.tensor([us], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        us = float(t.item())
+        recv = (world - 1) * logits.numel() * 4                   # bytes every rank receives per all-gather
+        allgather = {'allgather_us': us, 'bytes_per_rank': logits.numel() * 4, 'bytes_received_per_rank': recv,
+                     'allgather_GBps': recv / (us * 1e-6) / 1e9 if world > 1 else 0.0,
+                     'per_link_GBps': recv / (us * 1e-6) / 1e9 / max(world - 1, 1) if world > 1 else 0.0,
+                     'note': 'RCCL all_gather_into_tensor of fp32 logits, max over ranks, mean of 50 back-to-back calls; '
+                             'per_link = received bytes / (world - 1) point-to-point xGMI links'}
 
     if rank == 0:
+        value = world * args.batch * args.steps / elapsed
         out = {
             'metric': 'images/sec ResNet-18 LS-1w/LS-2a 224x224 eval forward' if args.act == 'ls-2' else
                       f'images/sec ResNet-18 ls-1w/{args.act}-a 224x224 eval forward',
-            'value': world * args.batch * args.steps / elapsed, 'unit': 'images/sec',
+            'value': value, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_step_min': group_ms[0], 'ms_per_step_median': group_ms[len(group_ms) // 2],
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'u64 popcount + f32', 'data': 'synthetic',
             'config': {'workload': f'ResNet-18 ImageNet ls-1 weight / {args.act} activation, '
                                    f'synthetic 3x224x224, batch {args.batch} per GPU, random-init weights',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world} (batch-sharded replicas, '
                                                                           'RCCL all-gather of logits)'},
+            'path_frac': value / world / PATH_ROOFLINE_IMG_S[args.act],
+            'path_frac_note': 'images/s per GPU / 628 k images/s = 8 TB/s over the 12.74 MB per image the 16 QuantConv2d '
+                              'layers read and write once (SURVEY 8(d)); popcount roofline 376 k images/s (ls-2)',
         }
         if not args.no_roofline:
-            launches, ms, nbytes, ops = _hip.drain_timing()[dominant]      # events over the timed region
-            kern = {}
-            for k, v in table.items():                                     # the instrumented step before it
-                kern[k] = {'launches_per_step': v[0], 'ms_per_step': v[1], 'algorithmic_GBps': v[2] / (v[1] * 1e-3) / 1e9}
-                if k == 'lsq_xnor_conv2d':      # VALU popcount: 2 ops / 32 MACs; v_bcnt_u32_b32 measured at half rate
-                    kern[k]['T_binary_MAC_per_s'] = v[3] / (v[1] * 1e-3) / 1e12
-                    kern[k]['frac_of_valu_popcount_peak_1258T'] = kern[k]['T_binary_MAC_per_s'] / 1258.0
-                if k == 'lsq_signw_conv2d':
-                    kern[k]['TFLOPs_bf16'] = v[3] / (v[1] * 1e-3) / 1e12
-            if dominant == 'lsq_signw_conv2d':
-                achieved = ops / (ms * 1e-3) / 1e12
-                out['roofline'] = {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': 2500.0,
-                                   'unit': 'TFLOP/s', 'frac': achieved / 2500.0, 'traffic': None}
-            else:
-                achieved = nbytes / (ms * 1e-3) / 1e9
-                out['roofline'] = {'bound': 'hbm', 'kernel': dominant, 'achieved': achieved, 'peak': 8000.0,
-                                   'unit': 'GB/s', 'frac': achieved / 8000.0, 'traffic': None}
-                if dominant == 'lsq_xnor_conv2d':
-                    out['roofline']['T_binary_MAC_per_s'] = ops / (ms * 1e-3) / 1e12
+            launches, ms, nbytes, ops = timed_table[dominant]               # events over the timed region
+            out['roofline'] = kernel_roofline(dominant, launches, ms, nbytes, ops)
+            out['roofline']['measured'] = 'HIP events around every launch of this kernel inside the timed region'
+            out['roofline']['traffic'] = None
             pmc = pmc_traffic_per_launch(dominant)
             if pmc:
                 out['roofline']['traffic'] = pmc['bytes_per_launch']
                 out['roofline']['traffic_note'] = ('HBM bytes per launch (all kernels of one call), rocprofv3 PMC passes in profiles/'
                                                    + pmc['source'] + '; algorithmic bytes per launch = %.4g' % (nbytes / launches))
-            out['roofline'].update(launches=launches, avg_launch_us=1e3 * ms / launches,
-                                   measured='HIP events around every launch of this kernel inside the timed region',
-                                   kernels=kern, kernels_measured='one fully instrumented step after the warm-up')
+            kern = {}
+            for k, v in table.items():                                     # the instrumented step before the timed region
+                kern[k] = kernel_roofline(k, *v)
+                kern[k]['ms_per_step'] = v[1]
+                kern[k]['launches_per_step'] = v[0]
+                p = pmc_traffic_per_launch(k)
+                if p:
+                    kern[k]['traffic'] = p['bytes_per_launch']
+                    kern[k]['algorithmic_bytes_per_launch'] = v[2] / max(v[0], 1)
+            out['roofline']['kernels'] = kern
+            out['roofline']['kernels_measured'] = 'one fully instrumented step after the warm-up'
+        if allgather is not None:
+            out['allgather'] = allgather
         if args.cpu_sample > 0 and world == 1:
             out['cpu_baseline'] = cpu_baseline(arch, model, args.cpu_sample)
+        if world == 1 and not args.no_configs and args.act == 'ls-2':
+            # the other single-GPU configurations BASELINE.json lists, as short legs of this process
+            del model
+            cfg = {}
+            m = build_model(imagenet_arch('fp', 2), device)
+            cfg['imagenet_ls1w_fpa_b256'] = config_leg('fp', m, x, 40, 5, 'ResNet-18 ImageNet ls-1 weight / fp activation '
+                                                       '(bf16 MFMA, hi+lo split), synthetic 3x224x224, batch 256', 80.4)
+            del m
+            m = build_model(cifar_arch(), device)
+            xc = torch.randn(100, 3, 32, 32, generator=torch.Generator().manual_seed(0)).to(device)
+            cfg['cifar100_ls1_kd_b100'] = config_leg('cifar', m, xc, 100, 5, 'ResNet-18 CIFAR-100 cifar100_ls1_kd (ls-1 weights and '
+                                                     'activations, clamp 2), synthetic 3x32x32, batch 100 (yaml test_batch_size)', 192.6)
+            del m
+            m = build_lenet(device)
+            xm = torch.randn(64, 1, 28, 28, generator=torch.Generator().manual_seed(0)).to(device)
+            cfg['mnist_lenet_ls1w_fpa_b64'] = config_leg('lenet', m, xm, 200, 5, 'LeNet-5 mnist_ls1_weight_fp_activation, synthetic '
+                                                         '1x28x28, batch 64', 19048.0)
+            out['configs'] = cfg
+            out['configs_note'] = ('value = images/sec of the eval forward, inputs resident in HBM; reference_cpu_images_per_sec_survey = '
+                                   'the reference itself on the 8 build-container cores (SURVEY section 6)')
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -1,20 +1,30 @@
 #!/bin/bash
-# Regenerate profiles/r<NN>_* on an MI355X box: both bench lines, the rocprofv3 kernel trace of bench.py
-# (whole-run stats + per-step summary of the timed steps) and the PMC HBM-traffic table.
-# usage (through gpurun): scripts/capture_profiles.sh r01   -> files under gpurun_out/, copy to profiles/
+# Regenerate profiles/r<NN>_* on an MI355X box: the bench lines, the rocprofv3 kernel trace of bench.py (whole-run
+# stats + per-step summary of the timed steps), the PMC HBM-traffic table (bench.py's own workload: the real network
+# with the folded batch norms), the SQ instruction counters of the XNOR conv, the micro-benchmarks the DESIGN.md
+# ceilings rest on (VALU issue rates, launch overhead) and the per-kernel micro-benchmark.
+# usage (through gpurun): scripts/capture_profiles.sh r02   -> files under gpurun_out/, copy to profiles/
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-tag=${1:-r01}; o=gpurun_out
+tag=${1:-r02}; o=gpurun_out
 mkdir -p $o
 python bench.py > $o/${tag}_bench_n1_ls2.json 2> $o/bench_ls2.err
-python bench.py --act fp > $o/${tag}_bench_n1_fpact.json 2> $o/bench_fp.err
+python bench.py --act fp --no-configs > $o/${tag}_bench_n1_fpact.json 2> $o/bench_fp.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 \
+  --steps 100 --cpu-sample 0 --no-configs > $o/${tag}_bench_torchrun_n1_ls2.json 2> $o/bench_torchrun.err
 rm -rf $o/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_final -- python bench.py --cpu-sample 0 > $o/prof_final.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_final -- python bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-configs > $o/prof_final.log 2>&1
 f=$(ls -t $o/prof_final/*/*kernel_trace.csv | head -1)
 python scripts/trace_summary.py $f 10 > $o/${tag}_rocprofv3_per_step_summary.csv
 cp $(ls -t $o/prof_final/*/*kernel_stats.csv | head -1) $o/${tag}_rocprofv3_kernel_stats_incl_warmup.csv
 rm -rf $o/prof_fp
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --cpu-sample 0 > $o/prof_fp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --steps 30 --warmup 5 --cpu-sample 0 --no-configs > $o/prof_fp.log 2>&1
 python scripts/trace_summary.py $(ls -t $o/prof_fp/*/*kernel_trace.csv | head -1) 10 > $o/${tag}_rocprofv3_per_step_summary_fpact.csv
 scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic.json > $o/pmc.log 2>&1
+scripts/pmc_kernel.sh xnor_conv xnor python scripts/xnor_one.py 64 56 64 1 > $o/${tag}_pmc_xnor_conv_C64_H56.txt 2>&1
+scripts/pmc_kernel.sh xnor_conv xnor512 python scripts/xnor_one.py 512 7 512 1 > $o/${tag}_pmc_xnor_conv_C512_H7.txt 2>&1
+for u in valu_rates launch_overhead; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o /tmp/$u 2> $o/$u.build.log && /tmp/$u > $o/${tag}_ubench_$u.txt 2>&1
+done
 python scripts/kbench.py > $o/${tag}_kbench.txt 2>&1
-head -3 $o/${tag}_rocprofv3_per_step_summary.csv; cut -c1-160 $o/${tag}_bench_n1_ls2.json; cut -c1-160 $o/${tag}_bench_n1_fpact.json
+python scripts/kbench.py --fold > $o/${tag}_kbench_bnfold.txt 2>&1
+head -3 $o/${tag}_rocprofv3_per_step_summary.csv; cut -c1-300 $o/${tag}_bench_n1_ls2.json; cut -c1-160 $o/${tag}_bench_n1_fpact.json

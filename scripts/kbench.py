@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--dist', default='gauss', choices=['gauss', 'relu', 'relu-bn'],
                     help='input distribution: N(0,1); relu(N(0,1)); per-channel affine of relu (what a BN after a ReLU feeds)')
+    ap.add_argument('--fold', action='store_true', help='fold a per-channel scale / shift into the quantizer read (as the network does)')
     args = ap.parse_args()
     dev = 'cuda:0'
     sch = {'ls-1': (1, 1), 'ls-2': (2, 2), 'ls-T': (3, 2), 'gf-2': (4, 2)}[args.scheme]
@@ -65,7 +66,10 @@ def main():
         ho, wo = _hip.out_hw(g)
         y = torch.empty((n, o, ho, wo), device=dev)
         bias = torch.zeros(o, device=dev)
-        tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales), args.iters)
+        pre = None
+        if args.fold:
+            pre = ((0.5 + torch.rand(c, device=dev)).contiguous(), (torch.randn(c, device=dev) * 0.3).contiguous())
+        tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales, pre=pre), args.iters)
         tc = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), args.iters)
         tf = timeit(lambda: _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y), args.iters)
         m = c * h * h
