@@ -97,7 +97,7 @@ def _cost_sq(matrix: torch.Tensor, v1s: torch.Tensor, ternary: bool) -> torch.Te
 def opt_v1(matrix: torch.Tensor, ternary: bool, skip: int = 1) -> torch.Tensor:
     """Optimal v1 per row of a 2-D tensor, searched over every ``skip``-th element. Returns [N, 1]."""
     with torch.no_grad():
-        if matrix.is_cuda:
+        if matrix.is_cuda and matrix.dtype == torch.float32:     # (other dtypes: the torch formulation below)
             from quant import _hip
             v12, _ = _hip.solve_rows(matrix, skip, ternary)
             return v12[0].view(-1, 1)

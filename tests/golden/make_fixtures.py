@@ -319,7 +319,66 @@ def f7_lenet():
     save('f7_lenet', **out)
 
 
+# ----------------------------------------------------------------------------- F8 moving-average modes + checkpoints
+def tiny_resnet_arch(mode, x_quant='ls-2'):
+    """A QResNet small enough for a fixture with the real structure (xnor blocks, double shortcuts, two
+    stride-2 stages with projection shortcuts; 16 / 32 / 64 channels, no fourth stage)."""
+    def layer():
+        return {'x_quant': x_quant, 'w_quant': 'ls-1', 'clamp': {'kind': 'symmetric', 'alpha': 3}, 'double_shortcut': True}
+    return {'moving_average_mode': mode, 'moving_average_momentum': 0.9, 'block': 'xnor',
+            'layer0': {'n_in_channels': 16, 'kernel_size': 3, 'stride': 1, 'padding': 1, 'bias': False,
+                       'maxpool': {'type': 'identity'}},
+            'layer1': layer(), 'layer2': layer(), 'layer3': layer(), 'layer4': None,
+            'nonlins': ['relu', 'relu'], 'num_blocks': [1, 1, 1], 'output_classes': 10}
+
+
+def f8_checkpoints():
+    """Reference models in the moving-average inference modes (activation_quantization.py:68-102): two train-mode
+    batches (weight scales cached, EMA of the activation scales and batch-norm statistics updated), the
+    reference's own log_checkpoints writes checkpoint_2.pt, then an eval-mode forward gives the expected logits.
+    The .pt files are what torch.save made of tensors and plain numbers (state dicts); no source."""
+    from pathlib import Path
+    from quant.utils.checkpoints import log_checkpoints
+    out = {}
+    ckdir = Path(HERE) / 'ref_checkpoints'
+    cases = [('resnet_eval_only_ls2', 'resnet', 'eval_only', 'ls-2'), ('resnet_train_and_eval_lsT', 'resnet', 'train_and_eval', 'ls-T'),
+             ('lenet_eval_only_ls2', 'lenet', 'eval_only', 'ls-2'), ('lenet_train_and_eval_gf2', 'lenet', 'train_and_eval', 'gf-2')]
+    for tag, kind, mode, xq in cases:
+        if kind == 'resnet':
+            arch = tiny_resnet_arch(mode, xq)
+            model = RefResNet(loss_fn=torch.nn.functional.cross_entropy, **arch)
+            shape = (6, 3, 32, 32)
+        else:
+            arch = arch_from_yaml('mnist/mnist_ls1_weight_ls2_activation.yaml')
+            arch.update(moving_average_mode=mode, moving_average_momentum=0.9, x_quant=xq, conv1_filters=8, conv2_filters=12)
+            model = RefLeNet(loss_fn=torch.nn.functional.nll_loss, **arch)
+            shape = (6, 1, 28, 28)
+        detgen.fill_module(model, seed=5)
+        model.train()
+        with torch.no_grad():
+            for b in range(2):
+                model(detgen.normal(f'{tag}.train{b}', shape))
+        opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+        sched = torch.optim.lr_scheduler.StepLR(opt, 1)
+        log_checkpoints(ckdir / tag / 'checkpoints', model, opt, sched, 2)
+        model.eval()
+        with torch.no_grad():
+            out[tag + '_logits'] = model(detgen.normal(f'{tag}.eval', shape))
+        out[tag + '_arch'] = np.frombuffer(json.dumps(arch).encode(), dtype=np.uint8)
+        sd = model.state_dict()
+        ma = [k for k in sd if k.endswith('moving_avg_module.moving_average')]
+        out[tag + '_ma_first'] = sd[ma[0]]
+        print(tag, 'checkpoint', os.path.getsize(ckdir / tag / 'checkpoints' / 'checkpoint_2.pt') // 1024, 'KiB')
+    save('f8_checkpoints', **out)
+
+
 if __name__ == '__main__':
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
+    f8_checkpoints()
     f1_sign()
     f24_quantizers()
     f3_solver()

@@ -343,3 +343,40 @@ def test_checkpoint_files_in_the_reference_layout(golden, tmp_path):
                                 get_path_to_checkpoint(tmp_path / 'exp'), torch.device('cpu'))
     restore_from_checkpoint(QLeNet5(loss_fn=None, w_quant='ls-2'), None, None,
                             get_path_to_checkpoint(tmp_path / 'exp'), torch.device('cpu'), strict_keys=False)
+
+
+def _restore_reference_checkpoint(golden, tag, device):
+    """Our model of the fixture's arch, restored (strict keys) from the checkpoint file the REFERENCE's
+    log_checkpoints wrote after two train-mode batches (tests/golden/make_fixtures.py f8_checkpoints)."""
+    import os
+    from quant.models.resnet import QResNet
+    from quant.utils.checkpoints import get_path_to_checkpoint, restore_from_checkpoint
+    g = golden('f8_checkpoints')
+    arch = g.json(tag + '_arch')
+    if tag.startswith('resnet'):
+        model, shape = QResNet(loss_fn=torch.nn.functional.cross_entropy, **arch), (6, 3, 32, 32)
+    else:
+        model, shape = QLeNet5(loss_fn=torch.nn.functional.nll_loss, **arch), (6, 1, 28, 28)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_checkpoints', tag)
+    model, _, _, epoch = restore_from_checkpoint(model.to(device), None, None, get_path_to_checkpoint(root), device)
+    assert epoch == 2
+    return model.eval(), detgen.normal(f'{tag}.eval', shape), g
+
+
+CHECKPOINT_TAGS = ['resnet_eval_only_ls2', 'resnet_train_and_eval_lsT', 'lenet_eval_only_ls2', 'lenet_train_and_eval_gf2']
+
+
+@pytest.mark.parametrize('tag', CHECKPOINT_TAGS)
+def test_reference_checkpoint_moving_average_inference(golden, tag):
+    """a checkpoint written by the reference in eval_only / train_and_eval mode
+    (activation_quantization.py:68-102, utils/checkpoints.py:17-51) loads with strict keys and the eval forward
+    -- activation scales = the restored moving averages, weight scales = the restored v1 buffers -- gives the
+    reference's logits."""
+    model, x, g = _restore_reference_checkpoint(golden, tag, torch.device('cpu'))
+    sd = model.state_dict()
+    ma = [k for k in sd if k.endswith('moving_avg_module.moving_average')]
+    assert torch.equal(sd[ma[0]], g[tag + '_ma_first'])
+    with torch.no_grad():
+        y = model(x)
+    ref = g[tag + '_logits']
+    assert y.shape == ref.shape and torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
