@@ -1,0 +1,149 @@
+"""yaml / CLI merge, metrics, the --skip-training evaluate loop and the driver scripts
+(reference quant/common/parser.py:196-261, metrics.py, training.py:155-204, tasks.py:85-232, examples/*/*.py)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import yaml
+
+import detgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# same sections and keys as the reference's examples/mnist/mnist_ls1_weight_ls2_activation.yaml
+CONFIG = {
+    'seed': None,
+    'environment': {'platform': 'local', 'ngpus': 1, 'cuda': {'cudnn_deterministic': True, 'cudnn_benchmark': False}},
+    'data': {'dataset_path': 'data/mnist/', 'train_batch_size': 64, 'test_batch_size': 50, 'workers': 4},
+    'model': {'architecture': 'lenet5', 'loss': 'nll_loss',
+              'arch_config': {'moving_average_mode': 'off', 'moving_average_momentum': 0.99, 'x_quant': 'ls-2',
+                              'w_quant': 'ls-1', 'clamp': {'kind': 'symmetric', 'alpha': 2}, 'conv1_filters': 20,
+                              'conv2_filters': 50, 'output_classes': 10}},
+    'optimization': {'epochs': 10, 'optimizer': {'algorithm': 'adadelta', 'lr': 1.0},
+                     'lr_scheduler': {'scheduler': 'step_lr', 'step_size': 1, 'gamma': 0.7}},
+    'log': {'level': 'INFO', 'interval': 10, 'tensorboard': True},
+}
+
+
+def _write(tmp_path, cfg=CONFIG, name='mnist_ls2.yaml'):
+    path = tmp_path / name
+    path.write_text(yaml.safe_dump(cfg))
+    return str(path)
+
+
+def test_parse_config_merges_yaml_and_flags(tmp_path):
+    from quant.common.parser import get_base_argument_parser, parse_config
+    parser = get_base_argument_parser('test')
+    cfg = parse_config(parser.parse_args(['--config', _write(tmp_path), '--ngpus', '0', '--skip-training']))
+    assert cfg['environment']['ngpus'] == 0 and cfg['skip_training'] is True            # the flag beats the file
+    assert cfg['experiment_name'].endswith('_mnist_ls2') and cfg['config'].endswith('mnist_ls2.yaml')
+    assert cfg['model']['arch_config']['x_quant'] == 'ls-2' and 'init_from_checkpoint' not in cfg
+    cfg = parse_config(parser.parse_args(['--config', _write(tmp_path), '--experiment-name', 'exp7',
+                                          '--init-from-checkpoint', 'ck.pt']))
+    assert cfg['experiment_name'] == 'exp7' and cfg['environment']['ngpus'] == 1 and cfg['skip_training'] is False
+    assert cfg['init_from_checkpoint'] == 'ck.pt'
+    bare = {k: v for k, v in CONFIG.items() if k != 'environment'}                       # no environment section
+    cfg = parse_config(parser.parse_args(['--config', _write(tmp_path, bare, 'bare.yaml')]))
+    assert cfg['environment'] == {'platform': 'local', 'ngpus': 1 if torch.cuda.is_available() else 0}
+    with pytest.raises(ValueError):
+        parse_config(parser.parse_args([]))
+    with pytest.raises(ValueError):
+        parse_config(parser.parse_args(['--restore-experiment', 'x', '--init-from-checkpoint', 'y']))
+    # a restored experiment supplies the config
+    exp = tmp_path / 'old'
+    exp.mkdir()
+    (exp / 'config.yaml').write_text(yaml.safe_dump(dict(CONFIG, config='orig.yaml')))
+    cfg = parse_config(parser.parse_args(['--restore-experiment', str(exp), '--skip-training']))
+    assert cfg['restore_experiment'] == str(exp) and cfg['model']['architecture'] == 'lenet5'
+
+
+def test_metrics_match_direct_computation():
+    from quant.common.metrics import LossMetric, Top1Accuracy, TopKAccuracy
+    out = torch.log_softmax(detgen.normal('plumb.out', (37, 10)), dim=1)
+    tgt = torch.arange(37) % 10
+    loss, top1, top5 = LossMetric(torch.nn.functional.nll_loss, True), Top1Accuracy(True), TopKAccuracy(5, True)
+    for lo, hi in ((0, 16), (16, 32), (32, 37)):
+        for m in (loss, top1, top5):
+            m.update(out[lo:hi], tgt[lo:hi])
+    assert loss.compute() == pytest.approx(float(torch.nn.functional.nll_loss(out, tgt)), rel=1e-6)
+    assert top1.compute() == pytest.approx(float((out.argmax(1) == tgt).float().mean()))
+    assert top5.compute() == pytest.approx(float((out.topk(5, 1).indices == tgt.view(-1, 1)).any(1).float().mean()))
+    assert top1.n_examples == 37 and '/37 (' in str(top1)
+    last = Top1Accuracy(False)
+    last.update(out[:16], tgt[:16])
+    last.update(out[32:], tgt[32:])
+    assert last.n_examples == 5 and last.compute() == pytest.approx(float((out[32:].argmax(1) == tgt[32:]).float().mean()))
+    top1.reset()
+    assert top1.n_examples == 0
+
+
+def test_skip_training_task_and_checkpoint_on_cpu(tmp_path):
+    """tasks.py:185-194: model from the yaml model section, optional checkpoint, evaluate() over the test loader."""
+    from quant.common.experiment import Experiment, LocalComputePlatform
+    from quant.common.parser import get_base_argument_parser, parse_config
+    from quant.common.tasks import classification_task
+    from quant.data.data_loaders import MNISTDataLoader
+    from quant.models.lenet import QLeNet5
+    from quant.utils.checkpoints import log_checkpoints
+    src = QLeNet5(loss_fn=torch.nn.functional.nll_loss, **CONFIG['model']['arch_config'])
+    detgen.fill_module(src, seed=12)
+    with torch.no_grad():
+        src.conv2.w_approximate.v1.copy_(src.conv2.weight.abs().mean(dim=(1, 2, 3)))
+    opt = torch.optim.SGD(src.parameters(), lr=0.1)
+    log_checkpoints(tmp_path / 'ck', src, opt, torch.optim.lr_scheduler.StepLR(opt, 1), 4)
+    parser = get_base_argument_parser('t')
+    cfg = parse_config(parser.parse_args(['--config', _write(tmp_path), '--ngpus', '0', '--skip-training', '--experiment-name',
+                                          'e1', '--init-from-checkpoint', str(tmp_path / 'ck' / 'checkpoint_4.pt')]))
+    cfg['log']['root_experiments_dir'] = str(tmp_path)
+    train, test = LocalComputePlatform(str(tmp_path)).run(Experiment(classification_task, cfg, MNISTDataLoader))
+    assert train == [] and set(test[0]) == {'Loss', 'Top-1 Accuracy', 'Top-5 Accuracy'}
+    assert (tmp_path / 'experiments' / 'e1' / 'config.yaml').exists()
+    # the same numbers by hand: the restored weights on the loader's synthetic test set
+    loader = MNISTDataLoader(**cfg['data']).get_test_loader()
+    src.eval()
+    with torch.no_grad():
+        outs, tgts = zip(*[(src(d), t) for d, t in loader])
+    out, tgt = torch.cat(outs), torch.cat(tgts)
+    assert len(tgt) == 200
+    assert test[0]['Top-1 Accuracy'] == pytest.approx(float((out.argmax(1) == tgt).float().mean()))
+    assert test[0]['Loss'] == pytest.approx(float(torch.nn.functional.nll_loss(out, tgt)), rel=1e-5)
+    cfg2 = dict(cfg, skip_training=False)
+    with pytest.raises(NotImplementedError):
+        classification_task(cfg2, tmp_path, MNISTDataLoader)
+
+
+def test_driver_script_runs_a_config(tmp_path):
+    cfg = json.loads(json.dumps(CONFIG))
+    cfg['data']['test_batch_size'] = 16
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'ml-quant_amd', 'examples', 'mnist.py'), '--config',
+                        _write(tmp_path, cfg), '--skip-training', '--ngpus', '0', '--experiment-name', 'drv'],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    metrics = json.loads(r.stdout.strip().splitlines()[-1])
+    assert set(metrics) == {'Loss', 'Top-1 Accuracy', 'Top-5 Accuracy'} and 0.0 <= metrics['Top-5 Accuracy'] <= 1.0
+
+
+@pytest.mark.gpu
+def test_skip_training_task_on_the_gpu(tmp_path):
+    """The same task with ngpus = 1: the evaluate loop drives the HIP path; metrics equal the CPU run's up to the
+    free-running parity of the ls-2 solve (top-k counts over random logits are robust to it)."""
+    from quant.common.tasks import classification_task
+    from quant.data.data_loaders import CIFAR100DataLoader
+    from quant.common.parser import get_base_argument_parser, parse_config
+    cfg = json.loads(json.dumps(CONFIG))
+    cfg['data'] = {'dataset_path': 'data/cifar100/', 'train_batch_size': 128, 'test_batch_size': 50, 'workers': 16}
+    layer = {'x_quant': 'ls-2', 'w_quant': 'ls-1', 'clamp': {'kind': 'symmetric', 'alpha': 2}, 'double_shortcut': True}
+    cfg['model'] = {'architecture': 'resnet', 'loss': 'cross_entropy', 'arch_config': {
+        'moving_average_mode': 'off', 'moving_average_momentum': 0.99, 'block': 'xnor',
+        'layer0': {'n_in_channels': 64, 'kernel_size': 3, 'stride': 1, 'padding': 1, 'bias': False, 'maxpool': {'type': 'identity'}},
+        'layer1': layer, 'layer2': layer, 'layer3': layer, 'layer4': layer, 'nonlins': ['relu', 'relu'],
+        'num_blocks': [2, 2, 2, 2], 'output_classes': 100}}
+    args = get_base_argument_parser('t').parse_args(['--config', _write(tmp_path, cfg, 'cifar.yaml'), '--skip-training', '--ngpus', '1'])
+    _, test = classification_task(parse_config(args), tmp_path, CIFAR100DataLoader)
+    assert set(test[0]) == {'Loss', 'Top-1 Accuracy', 'Top-5 Accuracy'} and test[0]['Loss'] > 0
+    assert 'liblsq_hip.so' in open('/proc/self/maps').read()
