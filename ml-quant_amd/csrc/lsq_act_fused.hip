@@ -1002,7 +1002,9 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, FusedLds
       w0[v][0] = w0[v][1] = w1[v][0] = w1[v][1] = 0u;
       facc[v] = 0.f;
     }
-    constexpr int UB = 32 / VEC;                       // loads per batch; two batches in flight
+    // loads per batch; two batches in flight.  One pixel per lane (the short rows): all 64 channels at once --
+    // those launches are bound by memory round trips per lane, not by bytes
+    constexpr int UB = VEC == 1 ? 64 : 32 / VEC;
     constexpr int NB = 64 / UB;
     float buf[2][UB][VEC];
     const float* __restrict__ q = src;                 // running channel pointer (no table of 64 addresses)
@@ -1169,7 +1171,9 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
     const unsigned nvec = (unsigned)(M / 4);
     const unsigned ntrip = (nvec + 2u) / 3u;
     const float hinv = 1.0f / (float)HW;
-    constexpr int B = 3;                               // triples in flight per lane
+    // triples in flight per lane (more in flight measured slower: the histogram atomics of a batch overlap the
+    // loads of the next one)
+    constexpr int B = 3;
 #pragma unroll
     for (int u0 = 0; u0 < U; u0 += B) {
       float4 v[B][3];

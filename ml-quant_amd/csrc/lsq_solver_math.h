@@ -128,22 +128,41 @@ __device__ inline bool run_has_candidate(double v, unsigned c, unsigned r0, doub
   if ((long long)r0 + tlo < 1) tlo = 1 - (long long)r0;
   if ((long long)r0 + thi > (long long)n - 2) thi = (long long)n - 2 - (long long)r0;
   if (tlo > thi) return false;
-  if (thi - tlo < 64) {
+  if (thi - tlo < 8) {
     for (long long t = tlo; t <= thi; ++t)
       if (position_is_candidate(v, v, (double)(r0 + t + 1), p0 + (double)(t + 1) * v, dn, total, ternary))
         return true;
     return false;
   }
-  // long runs: m2, m1 are monotone in t -> first t with m >= v must hit v exactly
+  // Longer runs: m2(t), m1(t) are monotone in t, so a run holds a candidate exactly when the FIRST t with m >= v
+  // has m == v.  With lo_cnt = k = r0 + t + 1 and lo_sum = A + k v (A = p0 - r0 v) both crossings are roots of
+  // linear equations in k:  m2 = v  <=>  k = (2 v n + A - total) / v,   m1 = v  <=>  k = A n / (v n + 2 A - total).
+  // The root brackets the first t to a window of four positions, which is then searched with the exact predicate
+  // (the same expressions as m_pair); a window that does not bracket (degenerate slopes: v = 0, all-equal rows)
+  // falls back to the bisection over the whole run.  Same answer as the bisection, a third of its divisions.
+  const double A = p0 - (double)r0 * v;
   for (int which = 0; which < (ternary ? 1 : 2); ++which) {
+    auto m_at = [&](long long t) {
+      const double lo_cnt = (double)(r0 + t + 1), lo_sum = p0 + (double)(t + 1) * v;
+      const double hi_mean = (total - lo_sum) / (dn - lo_cnt);
+      return which ? 0.5 * (lo_sum / lo_cnt + hi_mean) : 0.5 * hi_mean;
+    };
     long long lo = tlo, hi = thi;
+    const double kstar = which ? (A * dn) / (v * dn + 2.0 * A - total) : (2.0 * v * dn + A - total) / v;
+    if (kstar == kstar && kstar > -1e18 && kstar < 1e18) {
+      const long long tc = (long long)floor(kstar) - (long long)r0 - 1;
+      const long long wlo = tc - 1 < tlo ? tlo : (tc - 1 > thi ? thi : tc - 1);
+      const long long whi = tc + 2 < tlo ? tlo : (tc + 2 > thi ? thi : tc + 2);
+      if ((wlo == tlo || m_at(wlo - 1) < v) && (whi == thi || m_at(whi) >= v)) {
+        lo = wlo;
+        hi = whi;
+      }
+    }
     while (lo < hi) {
       const long long mid = (lo + hi) >> 1;
-      const MPair m = m_pair((double)(r0 + mid + 1), p0 + (double)(mid + 1) * v, dn, total);
-      if ((which ? m.m1 : m.m2) >= v) hi = mid; else lo = mid + 1;
+      if (m_at(mid) >= v) hi = mid; else lo = mid + 1;
     }
-    const MPair m = m_pair((double)(r0 + lo + 1), p0 + (double)(lo + 1) * v, dn, total);
-    if ((which ? m.m1 : m.m2) == v) return true;
+    if (m_at(lo) == v) return true;
   }
   return false;
 }
