@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 3
+#define LSQ_ABI_VERSION 4
 
 /* quantization schemes (quant/binary/binary_conv.py:99-101) */
 enum {
@@ -166,6 +166,18 @@ int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, 
  */
 int lsq_pool_bias_relu_nhwc(const float* x_nhwc, int N, int C, int H, int W, int kernel, int stride, int pad,
                             const float* bias, int relu, float* y_nchw, void* stream);
+
+/*
+ * ResNet stem in one kernel: y = max_pool2d(relu(conv2d(x, w, stride 2, padding 3) + bias), 3, 2, 1) for a
+ * 7x7 convolution from 3 to 64 channels whose eval-mode batch norm has been folded into w / bias by the caller.
+ * Replaces Sequential(conv1, bn1, relu, maxpool) of the reference's QResNet (quant/models/resnet.py: __init__
+ * layer0, forward :393-397) in front of the first QuantConv2d.  x [N,3,H,W] fp32 NCHW (W even, 8-byte aligned),
+ * w [64,3,7,7], bias [64], y [N,64,Hp,Wp] with Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (same for W).
+ * bf16 MFMA on operands split into `split` bf16 terms, fp32 accumulation: split = 3 (six passes, dropped terms
+ * <= 2^-24 relative per product: fp32 rounding level) or 2 (three passes, ~2^-17 relative per product).
+ */
+int lsq_stem_conv_pool(const float* x, int N, int H, int W, const float* w, const float* bias, int split,
+                       float* y, void* stream);
 
 #ifdef __cplusplus
 }

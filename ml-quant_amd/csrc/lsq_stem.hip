@@ -1,0 +1,277 @@
+// ResNet stem for gfx950 in ONE kernel: 7x7 stride-2 convolution (3 -> 64 channels, batch norm folded into the
+// weights) + bias + ReLU + 3x3 stride-2 max-pool, NCHW fp32 in, NCHW fp32 out.
+//
+// Replaces, in eval mode, Sequential(conv1, bn1, relu, maxpool) in front of the first quantized convolution
+// (quant/models/resnet.py: QResNet.__init__ / forward :393-397).  The previous path was three kernels -- a layout
+// change of the input to channels-last, MIOpen's fp32 implicit GEMM, and the pool / bias / ReLU tail -- with the
+// 112x112x64 convolution output (822 MB at batch 256) written to HBM and read back in between.  Here the
+// convolution output never leaves the chip.
+//
+// Arithmetic: bf16 MFMA (v_mfma_f32_32x32x16_bf16) on fp32 operands split into bf16 terms, fp32 accumulation.
+//   SPLIT = 3 (default): x = h + m + l (each the bf16 rounding of what is left; the remainders are exact in fp32),
+//     six passes hh + (hm + mh) + (hl + lh + mm); the dropped terms are <= 2^-24 relative per product, i.e. fp32
+//     rounding level -- a binarized network amplifies any perturbation in front of its first quantizer (one
+//     flipped sign is worth 3 % of a block's output), so the stem keeps fp32-class accuracy.
+//   SPLIT = 2: x = h + l, three passes hh + hl + lh, ~2^-17 relative per product, half the MFMA work.
+// Exact fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the VALU rate: 2.5x the cycles of the six bf16 passes.
+//
+// GEMM view: M = 64 out-channels (two 32-row tiles), N = output pixels (32-column tiles of one conv row),
+// K = (kh, c, kw) with kw padded 7 -> 8 so that the 8 k-values of one MFMA operand register group are EIGHT
+// CONSECUTIVE INPUT COLUMNS of one (kh, c) input row: K = 7 * 3 * 8 = 168 -> 11 steps of 16 (two input rows per
+// step; the 22nd row has zero weights).  The pad slot sits in FRONT (k = 0 is column 2x - 4, a zero weight), which
+// makes the operand start at an even bf16 index: four aligned ds_read_b32 per operand, conflict-free across the
+// 32 lanes (consecutive pixels = consecutive dwords).
+//
+// One 256-thread workgroup = one image x four pooled rows (nine conv rows: one halo row recomputed), walked in
+// chunks of 32 conv columns.  Per chunk: stage the 23 x 72 input patch of the three channels as bf16 hi / lo
+// planes in LDS; wave w owns out-channel tile w / 2 and conv rows w % 2, w % 2 + 2, ...: 66 (33) MFMAs per
+// row on two accumulators (leading products, cross terms); the three row-neighbours of each pixel are combined with two
+// cross-lane moves (horizontal 3-max, stride 2; the column left of the chunk comes from an LDS carry written by
+// the previous chunk) and the 16 x 9 x 64 partial maxima go to LDS; then all lanes take the vertical 3-max,
+// add the bias, apply the ReLU (both commute with the max) and store 64-byte segments of the NCHW output.
+
+#include "lsq_common.h"
+
+namespace lsq {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+union Frag {
+  unsigned u[4];
+  bf16x8 v;
+};
+
+// two fp32 values -> SPLIT packed bf16 pairs t[0] (leading term) .. t[SPLIT - 1]; x - t[0] - ... is exact in fp32
+template <int SPLIT>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&t)[SPLIT]) {
+  f32x2 r = {x0, x1};
+#pragma unroll
+  for (int i = 0; i < SPLIT; ++i) {
+    const bf16x2 b = __builtin_convertvector(r, bf16x2);
+    t[i] = __builtin_bit_cast(unsigned, b);
+    r = r - __builtin_convertvector(b, f32x2);
+  }
+}
+
+constexpr int kPH = 4;                    // pooled rows per workgroup
+constexpr int kCR = 2 * kPH + 1;          // conv rows per workgroup (one halo row)
+constexpr int kIR = 2 * kCR + 5;          // input rows per workgroup (23)
+constexpr int kIC = 72;                   // staged input columns per chunk: 2 * 32 + 5, padded to a multiple of 8
+constexpr int kSteps = 11;                // K = 176 = 11 x 16
+constexpr int kO = 64;
+
+struct StemArgs {
+  const float* x;      // [N][3][H][W]
+  const float* w;      // [64][3][7][7]  (batch norm folded)
+  const float* bias;   // [64]
+  float* y;            // [N][64][Hp][Wp]
+  int N, H, W, Hc, Wc, Hp, Wp;
+};
+
+template <int SPLIT>
+struct StemLds {
+  unsigned xs[SPLIT][3 * kIR * kIC / 2];  // bf16 pairs of each split term, [c][row][col]
+  float hbuf[kCR][kO][16];                // horizontal 3-max (stride 2) of every conv row of the chunk
+  float carry[kCR][2][2][16];             // last conv column of the previous chunk: [row][out-channel tile][lane half][reg]
+};
+
+template <int SPLIT>
+__global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   // two workgroups per CU: <= 256 registers (VGPR + AGPR)
+  __shared__ StemLds<SPLIT> lds;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int strips = (a.Hp + kPH - 1) / kPH;
+  const int n = blockIdx.x / strips;
+  const int pr0 = (blockIdx.x - n * strips) * kPH;
+  const int cr0 = 2 * pr0 - 1;            // first conv row of the strip (may be -1)
+  const int ir0 = 2 * cr0 - 3;            // first input row
+  const int mt = wid >> 1;                // out-channel tile
+  const int q0 = wid & 1;                 // first conv row of this wave
+  const int xl_ = lane & 31, g = lane >> 5;
+  const float ninf = -__builtin_inff();
+
+  // ---- A fragments (weights) of this wave's 32 out-channels, all 11 k-steps, hi and lo
+  Frag af[SPLIT][kSteps];
+  {
+    const int o = mt * 32 + xl_;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+      const int rr2 = 2 * s + g;          // (kh, c) row of K: kh = rr2 / 3, c = rr2 % 3; row 21 is padding
+      const int kh = rr2 / 3, c = rr2 - kh * 3;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (rr2 < 21 && j > 0) ? a.w[((o * 3 + c) * 7 + kh) * 7 + (j - 1)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned t[SPLIT];
+        split_pair<SPLIT>(v[2 * j], v[2 * j + 1], t);
+#pragma unroll
+        for (int i = 0; i < SPLIT; ++i) af[i][s].u[j] = t[i];
+      }
+    }
+  }
+  for (int i = tid; i < kCR * kO; i += 256) (&lds.carry[0][0][0][0])[i] = ninf;
+
+  const float* __restrict__ xn = a.x + (long long)n * 3 * a.H * a.W;
+  const int chunks = (a.Wc + 31) / 32;
+  for (int ck = 0; ck < chunks; ++ck) {
+    const int ic0 = 64 * ck - 4;          // input column of staged column 0
+    __syncthreads();                      // the previous chunk's patch and hbuf are done with
+    // ---- stage the input patch: pairs of columns, fp32 -> bf16 hi / lo.  Pair e = tid + 256 it of the
+    // [3][23][36] patch: 256 = 7 * 36 + 4, so (c, row, pair) advance without divisions; W is even and the patch
+    // starts at an even column, so a pair is inside the image or outside it as a whole.  All loads of a lane are
+    // issued before the first conversion.
+    {
+      constexpr int kPairs = 3 * kIR * (kIC / 2), kIt = (kPairs + 255) / 256, kHalf = 4;      // loads in flight per lane
+      int pp = tid % (kIC / 2), rr = tid / (kIC / 2), c = 0;
+#pragma unroll
+      for (int h0 = 0; h0 < kIt; h0 += kHalf) {
+        float2 t[kHalf];
+#pragma unroll
+        for (int it = h0; it < h0 + kHalf; ++it) {
+          if (it < kIt) {
+            const int ir = ir0 + rr, ic = ic0 + 2 * pp;
+            const bool in = tid + 256 * it < kPairs && ir >= 0 && ir < a.H && ic >= 0 && ic < a.W;
+            t[it - h0] = make_float2(0.f, 0.f);
+            if (in) t[it - h0] = *reinterpret_cast<const float2*>(xn + ((long long)c * a.H + ir) * a.W + ic);
+            pp += 4;
+            rr += 7;
+            if (pp >= kIC / 2) {
+              pp -= kIC / 2;
+              rr += 1;
+            }
+            if (rr >= kIR) {
+              rr -= kIR;
+              c += 1;
+            }
+          }
+        }
+#pragma unroll
+        for (int it = h0; it < h0 + kHalf; ++it) {
+          if (it < kIt && tid + 256 * it < kPairs) {
+            unsigned sp[SPLIT];
+            split_pair<SPLIT>(t[it - h0].x, t[it - h0].y, sp);
+#pragma unroll
+            for (int i = 0; i < SPLIT; ++i) lds.xs[i][tid + 256 * it] = sp[i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- this wave's conv rows of the chunk
+    for (int q = q0; q < kCR; q += 2) {
+      const int cr = cr0 + q;
+      if (cr < 0 || cr >= a.Hc) continue;                      // (wave-uniform) a padding row of the pool
+      f32x16 acc0 = {}, acc1 = {};        // leading products; all cross terms (<= 2^-8 of them: summed apart)
+      // B fragments: the reads of step s + 1 are issued before the MFMAs of step s (two register sets); the
+      // scheduling barriers keep it at two -- left alone, the scheduler hoists several steps' reads and spills
+      Frag bf[2][SPLIT];
+      auto load_b = [&](int s, int which) {
+        const int rr2 = min(2 * s + g, 20);
+        const int kh = rr2 / 3, c = rr2 - kh * 3;
+        const int off = ((c * kIR + 2 * q + kh) * kIC) / 2 + xl_;   // dword index: 2 * x bf16 = x dwords
+#pragma unroll
+        for (int i = 0; i < SPLIT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[which][i].u[j] = lds.xs[i][off + j];
+      };
+      load_b(0, 0);
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < kSteps) load_b(s + 1, (s + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const Frag* b = bf[s & 1];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[0].v, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[1].v, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[0].v, acc1, 0, 0, 0);
+        if constexpr (SPLIT == 3) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[2].v, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][s].v, b[0].v, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[1].v, acc1, 0, 0, 0);
+        }
+      }
+      // lane: pixel x = 32 ck + xl_, out-channels mt * 32 + (reg & 3) + 8 (reg >> 2) + 4 g.  Horizontal 3-max with
+      // stride 2: the neighbours come from wave-wide one-lane shifts (DPP, no LDS round trip); lanes 0 / 32 take
+      // their left neighbour -- the last column of the previous chunk -- from the carry, lanes 31 / 63 leave theirs.
+      const bool x_ok = 32 * ck + xl_ < a.Wc;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int ch = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
+        const float v = x_ok ? acc1[reg] + acc0[reg] : ninf;
+        const int vi = __float_as_int(v);
+        float left = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xF, 0xF, false));    // wave_shr:1
+        const float right = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xF, 0xF, false));   // wave_shl:1
+        if (xl_ == 0) left = lds.carry[q][mt][g][reg];
+        const float hmax = fmaxf(fmaxf(left, v), xl_ == 31 ? ninf : right);
+        if ((xl_ & 1) == 0) lds.hbuf[q][ch][xl_ >> 1] = hmax;
+        if (xl_ == 31) lds.carry[q][mt][g][reg] = v;        // (lanes 0 / 32 read theirs above)
+      }
+    }
+    __syncthreads();
+    // ---- vertical 3-max (stride 2), bias, ReLU, store: 64 channels x 4 pooled rows x 16 pooled columns
+    if ((a.Wp & 3) == 0) {
+      // four columns per lane: 16-byte LDS reads and global stores (a group of four is inside the row or outside it)
+      for (int e = tid; e < kO * kPH * 4; e += 256) {
+        const int j4 = e & 3, p = (e >> 2) & (kPH - 1), ch = e >> 4;
+        const int pr = pr0 + p, pc = 16 * ck + 4 * j4;
+        if (pr < a.Hp && pc < a.Wp) {
+          float4 m = make_float4(ninf, ninf, ninf, ninf);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int q = 2 * p + d, cr = cr0 + q;
+            if (cr >= 0 && cr < a.Hc) {
+              const float4 h = *reinterpret_cast<const float4*>(&lds.hbuf[q][ch][4 * j4]);
+              m.x = fmaxf(m.x, h.x); m.y = fmaxf(m.y, h.y); m.z = fmaxf(m.z, h.z); m.w = fmaxf(m.w, h.w);
+            }
+          }
+          const float b = a.bias[ch];
+          *reinterpret_cast<float4*>(a.y + (((long long)n * kO + ch) * a.Hp + pr) * a.Wp + pc) =
+              make_float4(fmaxf(m.x + b, 0.f), fmaxf(m.y + b, 0.f), fmaxf(m.z + b, 0.f), fmaxf(m.w + b, 0.f));
+        }
+      }
+    } else {
+      for (int e = tid; e < kO * kPH * 16; e += 256) {
+        const int j = e & 15, p = (e >> 4) & (kPH - 1), ch = e >> 6;
+        const int pr = pr0 + p, pc = 16 * ck + j;
+        if (pr < a.Hp && pc < a.Wp) {
+          float m = ninf;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const int q = 2 * p + d, cr = cr0 + q;
+            if (cr >= 0 && cr < a.Hc) m = fmaxf(m, lds.hbuf[q][ch][j]);
+          }
+          a.y[(((long long)n * kO + ch) * a.Hp + pr) * a.Wp + pc] = fmaxf(m + a.bias[ch], 0.f);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace lsq
+
+using namespace lsq;
+
+extern "C" int lsq_stem_conv_pool(const float* x, int N, int H, int W, const float* w, const float* bias, int split,
+                                  float* y, void* stream) {
+  if (!x || !w || !bias || !y) return LSQ_E_NULL;
+  if (N <= 0 || H < 8 || W < 8 || (W & 1) || ((uintptr_t)x % 8)) return LSQ_E_SHAPE;
+  if (split != 2 && split != 3) return LSQ_E_SCHEME;
+  StemArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.N = N; a.H = H; a.W = W;
+  a.Hc = (H + 6 - 7) / 2 + 1;
+  a.Wc = (W + 6 - 7) / 2 + 1;
+  a.Hp = (a.Hc + 2 - 3) / 2 + 1;
+  a.Wp = (a.Wc + 2 - 3) / 2 + 1;
+  const long long blocks = (long long)N * ((a.Hp + kPH - 1) / kPH);
+  if (blocks > 0x7FFFFFFF) return LSQ_E_SHAPE;
+  if (split == 3) hipLaunchKernelGGL(stem_conv_pool_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(stem_conv_pool_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -67,6 +67,8 @@ def _declare(lib):
     lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_pool_bias_relu_nhwc.restype = i32
     lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    lib.lsq_stem_conv_pool.restype = i32
+    lib.lsq_stem_conv_pool.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp]
 
 
 def lib():
@@ -273,4 +275,22 @@ def pool_bias_relu_nhwc(x: torch.Tensor, kernel: int, stride: int, pad: int, bia
         check(lib().lsq_pool_bias_relu_nhwc(x.data_ptr(), n, c, h, w, kernel, stride, pad,
                                             ptr(None if bias is None else _f32c(bias)), int(relu), y.data_ptr(),
                                             stream_ptr(x.device)), 'lsq_pool_bias_relu_nhwc')
+    return y
+
+
+def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: int = 3) -> torch.Tensor:
+    """``max_pool2d(relu(conv2d(x, w, stride=2, padding=3) + bias), 3, 2, 1)`` for a 7x7 convolution 3 -> 64
+    channels (batch norm already folded into ``w`` / ``bias``) as ONE kernel, NCHW fp32 in and out.  ``split``:
+    bf16 terms per fp32 operand (3: fp32-class accuracy, six MFMA passes; 2: ~2^-17 per product, three passes)."""
+    x, w, bias = _f32c(x), _f32c(w), _f32c(bias)
+    n, c, h, wd = x.shape
+    if c != 3 or tuple(w.shape) != (64, 3, 7, 7) or wd % 2:
+        raise LsqHipError('stem_conv_pool: 7x7 stride-2 convolution from 3 to 64 channels, even width')
+    hc, wc = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+    hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
+    y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device)
+    flops = 2 * (6 if split == 3 else 3) * n * 64 * hc * wc * 147      # bf16 passes issued
+    with _on(x), _Timed('lsq_stem_conv_pool', 4 * x.numel() + 4 * y.numel(), flops):
+        check(lib().lsq_stem_conv_pool(x.data_ptr(), n, h, wd, w.data_ptr(), bias.data_ptr(), int(split), y.data_ptr(),
+                                       stream_ptr(x.device)), 'lsq_stem_conv_pool')
     return y

@@ -59,6 +59,27 @@ def _square_pool(pool: nn.Module):
     return k[0], s[0], p[0]
 
 
+#: set to False to run the stem as MIOpen convolution + the pool / bias / ReLU tail kernel
+FUSED_STEM = True
+#: bf16 terms per fp32 operand in the fused stem: 3 = fp32-class accuracy (six MFMA passes, 0.70 ms at batch 256),
+#: 2 = ~2^-17 per product (three passes, 0.49 ms) -- measurably more sign flips in the first quantizers
+STEM_SPLIT = 3
+
+
+def _is_resnet_stem(conv: nn.Conv2d, relu: nn.Module, pool: nn.Module, x: torch.Tensor) -> bool:
+    """The ImageNet stem geometry lsq_stem_conv_pool implements: 7x7 / 2 / pad 3 from 3 to 64 channels, ReLU,
+    3x3 / 2 / pad 1 max-pool, fp32 NCHW input of even width."""
+    if not (isinstance(relu, nn.ReLU) and isinstance(pool, nn.MaxPool2d)):
+        return False
+    def two(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return (x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] == 3 and x.shape[3] % 2 == 0 and x.shape[2] >= 8
+            and conv.out_channels == 64 and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
+            and two(pool.kernel_size) == (3, 3) and two(pool.stride) == (2, 2) and two(pool.padding) == (1, 1)
+            and two(pool.dilation) == (1, 1) and not pool.ceil_mode)
+
+
 class _Stem(nn.Sequential):
     """``Sequential(conv1, bn1, relu, maxpool)`` of the reference (same keys).  Eval mode on the GPU: batch
     norm folded into the convolution's weights, MIOpen's convolution in channels-last, and the tail
@@ -69,6 +90,10 @@ class _Stem(nn.Sequential):
         conv, bn, relu, pool = self[0], self[1], self[2], self[3]
         if _eval_fold_ok(self, bn, x):
             w, b = _folded_conv_bn(self, conv, bn)
+            if FUSED_STEM and _is_resnet_stem(conv, relu, pool, x):
+                # conv + bias + ReLU + max-pool in one kernel (csrc/lsq_stem.hip): the 112x112x64 convolution
+                # output never goes to HBM, no channels-last copy of the input
+                return _hip.stem_conv_pool(x, w, b, STEM_SPLIT)
             # a per-channel bias commutes with max-pooling too: add it on the pooled (4x smaller) tensor.
             # MIOpen's 7x7 stride-2 convolution and the pooling are ~1.3x / ~1.9x faster in channels-last
             # (measured, scripts/stem_bench.py); the bias add writes the NCHW tensor the quantizer reads.
