@@ -179,6 +179,16 @@ int lsq_pool_bias_relu_nhwc(const float* x_nhwc, int N, int C, int H, int W, int
 int lsq_stem_conv_pool(const float* x, int N, int H, int W, const float* w, const float* bias, int split,
                        float* y, void* stream);
 
+/*
+ * Strided 1x1 convolution: y[n][o][ho][wo] = sum_c w[o][c] * x[n][c][ho*stride][wo*stride] + bias[o], the projection
+ * shortcut Sequential(Conv2d(in, out, 1, stride), BatchNorm2d(out)) of the reference's residual blocks
+ * (quant/models/resnet.py: XnorBasicBlock / RegularBasicBlock, forward :180-190) with the eval-mode batch norm
+ * folded into w / bias by the caller.  x [N,C,H,W], w [O,C], y [N,O,Ho,Wo] fp32 NCHW, Ho = (H-1)/stride + 1;
+ * C and O multiples of 64 (LSQ_E_UNSUPPORTED otherwise); bias may be NULL.  Exact fp32 (fp32 MFMA).
+ */
+int lsq_pointwise_conv(const float* x, int N, int C, int H, int W, const float* w, const float* bias, int O,
+                       int stride, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ def _declare(lib):
     lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_pool_bias_relu_nhwc.restype = i32
     lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
+    lib.lsq_pointwise_conv.restype = i32
+    lib.lsq_pointwise_conv.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.lsq_stem_conv_pool.restype = i32
     lib.lsq_stem_conv_pool.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp]
 
@@ -293,4 +295,17 @@ def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: 
     with _on(x), _Timed('lsq_stem_conv_pool', 4 * x.numel() + 4 * y.numel(), flops):
         check(lib().lsq_stem_conv_pool(x.data_ptr(), n, h, wd, w.data_ptr(), bias.data_ptr(), int(split), y.data_ptr(),
                                        stream_ptr(x.device)), 'lsq_stem_conv_pool')
+    return y
+
+
+def pointwise_conv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stride: int) -> torch.Tensor:
+    """``conv2d(x, w[:, :, None, None], bias, stride)`` for a 1x1 kernel (the projection shortcut, batch norm
+    already folded), NCHW fp32, exact fp32 on the matrix cores; C and O multiples of 64."""
+    x, w = _f32c(x), _f32c(w)
+    n, c, h, wd = x.shape
+    o = w.shape[0]
+    y = torch.empty((n, o, (h - 1) // stride + 1, (wd - 1) // stride + 1), dtype=torch.float32, device=x.device)
+    with _on(x), _Timed('lsq_pointwise_conv', 4 * (y.numel() // o) * c + 4 * y.numel(), 2 * y.numel() * c):
+        check(lib().lsq_pointwise_conv(x.data_ptr(), n, c, h, wd, w.data_ptr(), ptr(None if bias is None else _f32c(bias)), o,
+                                       int(stride), y.data_ptr(), stream_ptr(x.device)), 'lsq_pointwise_conv')
     return y

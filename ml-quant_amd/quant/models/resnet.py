@@ -123,6 +123,10 @@ class _ConvBN(nn.Sequential):
         if _eval_fold_ok(self, bn, x):
             w, b = _folded_conv_bn(self, conv, bn)
             if conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and x.dim() == 4:
+                if (x.dtype == torch.float32 and w.dtype == torch.float32 and conv.stride[0] == conv.stride[1]
+                        and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
+                    # the strided gather happens while staging the GEMM operand (csrc/lsq_pointwise.hip)
+                    return _hip.pointwise_conv(x, w.view(conv.out_channels, conv.in_channels), b, conv.stride[0])
                 return self._pointwise(x, w, b, conv.stride)
             return nn.functional.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
         return bn(conv(x))

@@ -31,7 +31,7 @@ def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         'lsq_abi_version', 'lsq_error_string', 'lsq_act_plane_words', 'lsq_weight_plane_words', 'lsq_solver_workspace_bytes',
         'lsq_act_quant', 'lsq_solve_rows', 'lsq_pack_weight', 'lsq_xnor_conv2d', 'lsq_signw_conv2d',
-                'lsq_pool_bias_relu_nhwc', 'lsq_stem_conv_pool'])
+                'lsq_pool_bias_relu_nhwc', 'lsq_stem_conv_pool', 'lsq_pointwise_conv'])
 
 
 def test_library_exports_every_declared_symbol(hip):
