@@ -10,10 +10,10 @@
 // GEMM operand, so x is read once, in place.
 //
 // GEMM view per workgroup: 64 out-channels x 64 pixels (flat index over n, ho, wo), K = C in chunks of 64 staged
-// in LDS as fp32: W chunk [64 o][64 c] (pitch 65: conflict-free column reads), X chunk [64 c][64 pixels].  Each of
-// the four waves owns one 32 x 32 tile; an MFMA takes ONE fp32 per lane per operand (A[o = lane & 31][k = lane >> 5],
-// B[k = lane >> 5][pixel = lane & 31]).  The work is small (10 GFLOP per forward): the kernel is bound by the
-// strided read of x and the write of y.
+// in LDS as fp32, both operands channel-minor: W chunk [64 o][64 c], X chunk [64 pixels][64 c].  Each of the four
+// waves owns one 32 x 32 tile; an MFMA takes ONE fp32 per lane per operand (A[o = lane & 31][k = lane >> 5],
+// B[k = lane >> 5][pixel = lane & 31]), fetched 32 at a time with ds_read_b128.  The global loads of chunk i + 1 are
+// in flight during the MFMAs of chunk i.  The work is small (10 GFLOP per forward, 63 us at the fp32 MFMA peak).
 
 #include "lsq_common.h"
 
@@ -31,58 +31,91 @@ struct PwArgs {
   long long P;         // N * Ho * Wo
 };
 
+constexpr int kPitch = 68;   // floats per LDS row: 16-byte aligned rows, ds_read_b128 of 16 consecutive rows conflict-free
+
 __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
-  __shared__ float ws[64][65];
-  __shared__ float xs[64][64];
+  __shared__ __attribute__((aligned(16))) float ws[64][kPitch];   // [out-channel][channel]
+  __shared__ __attribute__((aligned(16))) float xs[64][kPitch];   // [pixel][channel]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const long long p0 = (long long)blockIdx.x * 64;
-  const int o0 = blockIdx.y * 64;
+  // out-channel tile = fast index: the O / 64 workgroups that read the same pixels are dispatched together, so
+  // the strided x tile comes from HBM once and from L2 afterwards
+  const unsigned n_ot = (unsigned)a.O >> 6;
+  const long long p0 = (long long)(blockIdx.x / n_ot) * 64;
+  const int o0 = (int)(blockIdx.x % n_ot) * 64;
   const int HoWo = a.Ho * a.Wo;
   const long long HW = (long long)a.H * a.W;
-  // staging role: pixel column tid & 63, channel rows tid >> 6, +4, ...
-  const int spx = tid & 63;
-  const long long sp = p0 + spx;
-  const bool sp_ok = sp < a.P;
-  const long long spc = sp_ok ? sp : a.P - 1;
-  const int sn = (int)(spc / HoWo);
-  const int sr = (int)(spc - (long long)sn * HoWo);
+  // staging role: pixel column `lane`, wave w brings channels 16 w .. 16 w + 15 of the chunk (pixels past the end
+  // are clamped to the last one: loaded, multiplied, never stored -- no branch around any load)
+  const long long sp = min(p0 + lane, a.P - 1);
+  const int sn = (int)(sp / HoWo);
+  const int sr = (int)(sp - (long long)sn * HoWo);
   const int sho = sr / a.Wo, swo = sr - sho * a.Wo;
-  const float* __restrict__ xsrc = a.x + (long long)sn * a.C * HW + (long long)sho * a.s * a.W + swo * a.s;
+  // (addresses = workgroup-uniform 64-bit base + one 32-bit offset per lane: the entry point admits tensors below
+  // 2^30 elements; 64-bit per-lane addresses for 32 loads in flight would cost 64 VGPRs)
+  const unsigned xoff = (unsigned)(((long long)sn * a.C + 16 * wid) * HW + (long long)sho * a.s * a.W + swo * a.s);
+  const float* __restrict__ xsrc = a.x;
+  // W chunk: consecutive lanes -> consecutive channels of one out-channel row; wave w brings rows 16 w .. 16 w + 15
+  const unsigned woff = (unsigned)(16 * wid * a.C + lane);
+  const float* __restrict__ wsrc = a.w + (long long)o0 * a.C;
   // compute role: out-channel tile mt, pixel tile nt
   const int mt = wid >> 1, nt = wid & 1;
   const int col = lane & 31, g = lane >> 5;
   f32x16 acc = {};
+  float xv[16], wv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) xv[i] = (xsrc + (long long)i * HW)[xoff];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) wv[i] = (wsrc + (long long)i * a.C)[woff];
   for (int c0 = 0; c0 < a.C; c0 += 64) {
+    __syncthreads();                       // the fragments of the previous chunk have been read
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(&xs[lane][16 * wid + 4 * q]) = make_float4(xv[4 * q], xv[4 * q + 1], xv[4 * q + 2], xv[4 * q + 3]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ws[16 * wid + i][lane] = wv[i];
     __syncthreads();
-    // X chunk: 16 loads per lane, all issued before the first LDS write
-    float xv[16];
+    if (c0 + 64 < a.C) {                   // the next chunk's loads fly during this chunk's MFMAs
 #pragma unroll
-    for (int i = 0; i < 16; ++i) xv[i] = sp_ok ? xsrc[(long long)(c0 + 4 * i + (tid >> 6)) * HW] : 0.f;
-    // W chunk: consecutive lanes -> consecutive channels of one out-channel row
-    float wv[16];
+      for (int i = 0; i < 16; ++i) xv[i] = (xsrc + (long long)(c0 + 64 + i) * HW)[xoff];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) wv[i] = a.w[(long long)(o0 + 4 * i + (tid >> 6)) * a.C + c0 + spx];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      xs[4 * i + (tid >> 6)][spx] = xv[i];
-      ws[4 * i + (tid >> 6)][spx] = wv[i];
+      for (int i = 0; i < 16; ++i) wv[i] = (wsrc + (long long)i * a.C + c0 + 64)[woff];
     }
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 64; k += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws[mt * 32 + col][k + g], xs[k + g][nt * 32 + col], acc, 0, 0, 0);
+    // MFMA step s multiplies channel 32 g + s of the chunk (any assignment of channels to steps is a valid GEMM as
+    // long as both operands use the same one): a lane's 32 operands per matrix are 128 contiguous bytes
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 af[4], bf[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        af[q] = *reinterpret_cast<const float4*>(&ws[mt * 32 + col][32 * g + 16 * h + 4 * q]);
+        bf[q] = *reinterpret_cast<const float4*>(&xs[nt * 32 + col][32 * g + 16 * h + 4 * q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[q].w, acc, 0, 0, 0);
+      }
+    }
   }
   // lane: pixel p0 + nt * 32 + col, out-channels o0 + mt * 32 + (reg & 3) + 8 (reg >> 2) + 4 g
   const long long p = p0 + nt * 32 + col;
+  const int ob = o0 + mt * 32 + 4 * g;
+  float bv[16];
+  if (a.bias) {                            // (uniform) all bias loads before the first store
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) bv[reg] = a.bias[ob + (reg & 3) + 8 * (reg >> 2)];
+  } else {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) bv[reg] = 0.f;
+  }
   if (p >= a.P) return;
   const int n = (int)(p / HoWo);
   const int r = (int)(p - (long long)n * HoWo);
-  float* __restrict__ yp = a.y + ((long long)n * a.O + o0 + mt * 32 + 4 * g) * HoWo + r;
+  const unsigned yoff = (unsigned)(((long long)n * a.O + ob) * HoWo + r);
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int orow = (reg & 3) + 8 * (reg >> 2);
-    yp[(long long)orow * HoWo] = acc[reg] + (a.bias ? a.bias[o0 + mt * 32 + 4 * g + orow] : 0.f);
-  }
+  for (int reg = 0; reg < 16; ++reg) (a.y + (long long)((reg & 3) + 8 * (reg >> 2)) * HoWo)[yoff] = acc[reg] + bv[reg];
 }
 
 }  // namespace
@@ -95,6 +128,8 @@ extern "C" int lsq_pointwise_conv(const float* x, int N, int C, int H, int W, co
   if (!x || !w || !y) return LSQ_E_NULL;
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || stride <= 0) return LSQ_E_SHAPE;
   if (C % 64 || O % 64) return LSQ_E_UNSUPPORTED;
+  if ((long long)N * C * H * W >= (1ll << 30) || (long long)N * O * ((H - 1) / stride + 1) * ((W - 1) / stride + 1) >= (1ll << 30))
+    return LSQ_E_UNSUPPORTED;              // 32-bit lane offsets
   PwArgs a = {};
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   a.N = N; a.C = C; a.H = H; a.W = W; a.O = O; a.s = stride;
@@ -102,7 +137,7 @@ extern "C" int lsq_pointwise_conv(const float* x, int N, int C, int H, int W, co
   a.Wo = (W - 1) / stride + 1;
   a.P = (long long)N * a.Ho * a.Wo;
   const long long blocks = (a.P + 63) / 64;
-  if (blocks > 0x7FFFFFFF) return LSQ_E_SHAPE;
-  hipLaunchKernelGGL(pointwise_conv_kernel, dim3((unsigned)blocks, (unsigned)(O / 64)), dim3(256), 0, (hipStream_t)stream, a);
+  if (blocks * (O / 64) > 0x7FFFFFFF) return LSQ_E_SHAPE;
+  hipLaunchKernelGGL(pointwise_conv_kernel, dim3((unsigned)(blocks * (O / 64))), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

@@ -111,6 +111,13 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
   unsigned long long xn[KX];
 #pragma unroll
   for (int p = 0; p < KX; ++p) xn[p] = xp[p * plane_stride + a.tap_xoff[0]];
+  // OT = 8: weight words one step ahead as well (scalar loads return out of order, so the only usable wait is
+  // "all of them"; issued a whole step early, that wait finds them there).  With 16 channels per lane two sets
+  // of weight words do not fit the 102 SGPRs.
+  constexpr bool kWeightsAhead = OT <= 8;
+  unsigned long long wnext[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) wnext[o] = kWeightsAhead ? wbase[o] : 0ull;
   for (int j = 0; j < a.Gg; ++j) {
     const unsigned long long* __restrict__ wp = wbase + j * a.opad_total;
     for (int tp = 0; tp < taps; ++tp) {
@@ -130,7 +137,13 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
       // accumulator end up 2*OT*KX instructions apart instead of back to back (v_bcnt is a 2-pass op)
       unsigned long long wv[OT];
 #pragma unroll
-      for (int o = 0; o < OT; ++o) wv[o] = wp[o];            // wave-uniform: scalar loads, SGPR operands
+      for (int o = 0; o < OT; ++o) wv[o] = kWeightsAhead ? wnext[o] : wp[o];   // wave-uniform: scalar loads, SGPR operands
+      if (kWeightsAhead) {
+        const bool last_tap = tp + 1 == taps;
+        const unsigned long long* __restrict__ wq = last_tap ? wbase + (j + 1 < a.Gg ? j + 1 : j) * a.opad_total : wp + wstep;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) wnext[o] = wq[o];       // (the very last step re-reads a valid address)
+      }
 #pragma unroll
       for (int o = 0; o < OT; ++o) {
 #pragma unroll

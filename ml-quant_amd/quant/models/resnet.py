@@ -124,7 +124,8 @@ class _ConvBN(nn.Sequential):
             w, b = _folded_conv_bn(self, conv, bn)
             if conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and x.dim() == 4:
                 if (x.dtype == torch.float32 and w.dtype == torch.float32 and conv.stride[0] == conv.stride[1]
-                        and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
+                        and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+                        and max(x.numel(), x.numel() // conv.in_channels * conv.out_channels) < 2 ** 30):
                     # the strided gather happens while staging the GEMM operand (csrc/lsq_pointwise.hip)
                     return _hip.pointwise_conv(x, w.view(conv.out_channels, conv.in_channels), b, conv.stride[0])
                 return self._pointwise(x, w, b, conv.stride)
