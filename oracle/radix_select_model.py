@@ -1,13 +1,18 @@
-"""Host model (numpy) of the GPU optimal-v1 solver's algorithm -- TEST INFRASTRUCTURE ONLY.
+"""Host model (numpy) of the sort-free idea behind the GPU optimal-v1 solver -- TEST INFRASTRUCTURE ONLY.
 
-The HIP solver (ml-quant_amd/csrc/lsq_act_quant.hip) never sorts a row.  It finds the
-reference's candidate positions (quant/binary/optimal.py:55-83) with a three-level
-radix select over the IEEE-754 bit pattern of |x| (12 + 10 + 9 bits) in which every
-histogram bin carries an *exact integer* sum of its elements, so rank and prefix sum at
-any bin boundary are exact; only bins that can contain a crossing of the monotone
-functions m1(i), m2(i) with the sorted sequence are refined.  This file states that
-algorithm step by step so its logic (bounds, successor handling, edge cases) can be
-checked on the CPU against ``oracle/lsq_exact.py``; the HIP kernel is a transcription of it.
+The HIP solvers (ml-quant_amd/csrc/lsq_act_fused.hip, lsq_act_quant.hip, shared math in
+lsq_solver_math.h) never sort a row.  They find the reference's candidate positions
+(quant/binary/optimal.py:55-83) with a radix select over the IEEE-754 bit pattern of |x| in
+which every histogram bin carries an *exact integer* sum of its elements, so rank and prefix sum
+at any bin boundary are exact; only bins that can contain a crossing of the monotone functions
+m1(i), m2(i) with the sorted sequence are refined.  This file states that idea step by step with a
+fixed three-level split (12 + 10 + 9 key bits) so that its logic (conservative bin test, successor
+handling, runs of equal keys, edge cases) can be checked on the CPU against ``oracle/lsq_exact.py``.
+
+It is NOT a transcription of the shipped kernels: those use a 13-bit first level, 6-bit refinement
+rounds over an LDS key list, brute-force ranking of small sub-bins and a closed-form test for
+runs; their results are checked bit for bit against ``oracle/lsq_exact.py`` on the device
+(tests/test_gpu_parity.py), not against this model.
 """
 
 from __future__ import annotations
@@ -16,7 +21,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-L1_SHIFT, L2_SHIFT = 19, 9          # 12 + 10 + 9 key bits, as in the kernel
+L1_SHIFT, L2_SHIFT = 19, 9          # 12 + 10 + 9 key bits (this model's split)
 L2_BITS, L3_BITS = 10, 9
 KEY_INF = 0xFFFFFFFF
 SLACK = 1e-9
