@@ -66,3 +66,9 @@ def test_cuda_path_has_no_fallback(monkeypatch, hip):
     monkeypatch.setattr(hip, '_LIB_PATH', '/nonexistent/liblsq_hip.so')
     with pytest.raises(hip.LsqHipError):
         hip.lib()
+
+
+def test_build_entry_point_checks_the_current_abi():
+    """__graft_entry__.build() (what the driver runs) compiles, loads and checks the ABI version and exports."""
+    import __graft_entry__
+    __graft_entry__.build()
