@@ -17,6 +17,7 @@
 // for every out-of-image tap of a border pixel, which makes the result exact.
 
 #include "lsq_common.h"
+#include "lsq_xnor_conv.h"
 
 #include <cstdlib>
 
@@ -24,26 +25,6 @@ namespace lsq {
 namespace {
 
 constexpr int kDefaultOT = 16;
-
-struct ConvArgs {
-  const unsigned long long* xplanes;   // [KX][N][Gt][Hp][Wp]
-  const float* xscales;                // [KX][N]
-  const unsigned long long* wbits;     // [taps][Gg][Opad]  (one weight plane)
-  const int* wsum;                     // [O][taps]
-  const float* wscale;                 // [O]
-  const float* bias;                   // [O] or null
-  float* y;                            // [N][O][Ho][Wo]
-  long long xplane_words;
-  int N, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
-  int Gg, Gt, Hp, Wp, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
-  int accumulate;
-  int final_pass;                      // last launch of a multi-plane sequence: apply the epilogue
-  int relu;                            // epilogue: y = relu(conv + bias + res_pre) + res_post
-  const float* res_pre;                // [N][O][Ho][Wo] or null
-  const float* res_post;
-  int dbg_no_corr;                     // tuning builds only
-  int tap_xoff[64];                    // (kh*dil_h)*Wp + kw*dil_w per tap
-};
 
 template <int KX, int OT>
 __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
@@ -262,6 +243,10 @@ int launch_kx(ConvArgs a, int groups, hipStream_t st) {
 
 using namespace lsq;
 
+static int g_force_popcount = 0;
+// test / profiling switch (not part of the contract): 1 = every geometry through the popcount kernel
+extern "C" void lsq_debug_xnor_impl(int popcount_only) { g_force_popcount = popcount_only; }
+
 extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
                                const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
                                const lsq_conv_geom* g, int relu, const float* res_pre, const float* res_post,
@@ -306,7 +291,8 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
       a.wscale = wscales + (long long)q * g->O;
       a.accumulate = first ? 0 : 1;
       a.final_pass = (q == kw_planes - 1 && p0 + np >= kx) ? 1 : 0;
-      const int e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
+      int e = g_force_popcount ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
+      if (e == kXnorMfmaNotEligible) e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
       if (e) return e;
       first = false;
     }

@@ -309,3 +309,9 @@ def pointwise_conv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         check(lib().lsq_pointwise_conv(x.data_ptr(), n, c, h, wd, w.data_ptr(), ptr(None if bias is None else _f32c(bias)), o,
                                        int(stride), y.data_ptr(), stream_ptr(x.device)), 'lsq_pointwise_conv')
     return y
+
+
+def xnor_impl(popcount_only: bool) -> None:
+    """Test / profiling switch: route every XNOR convolution through the popcount kernel (True) or let the
+    dispatcher pick the integer-MFMA kernel where it applies (False, the default)."""
+    lib().lsq_debug_xnor_impl(int(bool(popcount_only)))

@@ -45,7 +45,9 @@ def main():
     ap.add_argument('--dist', default='gauss', choices=['gauss', 'relu', 'relu-bn'],
                     help='input distribution: N(0,1); relu(N(0,1)); per-channel affine of relu (what a BN after a ReLU feeds)')
     ap.add_argument('--fold', action='store_true', help='fold a per-channel scale / shift into the quantizer read (as the network does)')
+    ap.add_argument('--xnor-popcount', action='store_true', help='every XNOR convolution through the popcount kernel')
     args = ap.parse_args()
+    _hip.xnor_impl(args.xnor_popcount)
     dev = 'cuda:0'
     sch = {'ls-1': (1, 1), 'ls-2': (2, 2), 'ls-T': (3, 2), 'gf-2': (4, 2)}[args.scheme]
     n = args.batch
