@@ -39,12 +39,17 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
   constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (tap, word, half of the dword's bits)
   constexpr int NW = TAPS * GG * KX;             // activation dwords per lane and tile
   __shared__ v4i s_w[NF][64];
-  __shared__ int s_ws[TAPS][32], s_rs[8][32], s_cs[8][32], s_tot[32];
+  __shared__ int s_ws[TAPS][32];
+  // fc[bad rows][bad columns][o] = sum of wsum over the taps OUTSIDE the image - sum over all taps: what a pixel
+  // with that border pattern adds to 2 * (matrix-core sum).  3 x 3 taps: 8 x 8 patterns, one table look-up per
+  // output instead of loops over kernel rows and columns.
+  __shared__ __attribute__((aligned(16))) int s_fc[8][8][32];
+  __shared__ __attribute__((aligned(16))) float s_scale[32], s_bias[32];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int o0 = blockIdx.y * 32;
 
-  // ---- once per workgroup: weight fragments and halo tables of its 32 out-channels -------------------------------
+  // ---- once per workgroup: weight fragments and epilogue tables of its 32 out-channels ----------------------------
   for (int e = tid; e < NF * 256; e += 256) {
     const int r = e & 3, L = (e >> 2) & 63, f = e >> 8;
     const int q = 4 * (f & 1) + r;
@@ -57,20 +62,20 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
     reinterpret_cast<unsigned*>(&s_w[f][L])[r] = out;
   }
   for (int i = tid; i < TAPS * 32; i += 256) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
+  if (tid < 32) {
+    s_scale[tid] = a.wscale[o0 + tid];
+    s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
+  }
   __syncthreads();
-  for (int i = tid; i < (a.KH + a.KW + 1) * 32; i += 256) {
-    const int k = i >> 5, o = i & 31;
-    int acc_s = 0;
-    if (k < a.KH) {
-      for (int kw = 0; kw < a.KW; ++kw) acc_s += s_ws[k * a.KW + kw][o];
-      s_rs[k][o] = acc_s;
-    } else if (k < a.KH + a.KW) {
-      for (int kh = 0; kh < a.KH; ++kh) acc_s += s_ws[kh * a.KW + (k - a.KH)][o];
-      s_cs[k - a.KH][o] = acc_s;
-    } else {
-      for (int tp = 0; tp < TAPS; ++tp) acc_s += s_ws[tp][o];
-      s_tot[o] = acc_s;
+  for (int i = tid; i < 8 * 8 * 32; i += 256) {
+    const int o = i & 31, bw = (i >> 5) & 7, bh = i >> 8;
+    int v = 0;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const bool outside = ((bh >> (tp / 3)) & 1) | ((bw >> (tp % 3)) & 1);
+      v -= outside ? 0 : s_ws[tp][o];
     }
+    s_fc[bh][bw][o] = v;
   }
   __syncthreads();
   v4i wreg[NF];
@@ -78,29 +83,43 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
   for (int f = 0; f < NF; ++f) wreg[f] = s_w[f][lane];
 
   // ---- tiles ------------------------------------------------------------------------------------------------------
-  const long long total = (long long)a.N * a.Ho * a.Wo;
-  const int ntiles = (int)((total + 31) >> 5);
+  const unsigned total = (unsigned)(a.N * a.Ho * a.Wo);
+  const int ntiles = (int)((total + 31u) >> 5);
   const int HoWo = a.Ho * a.Wo;
   const int HpWp = a.Hp * a.Wp;
   const unsigned* __restrict__ xd = reinterpret_cast<const unsigned*>(a.xplanes);
   const unsigned plane_stride = 2u * (unsigned)a.xplane_words;
   const int tstride = gridDim.x * 4;
+  // a wave's pixel index advances by the same amount from tile to tile: (n, ho, wo) follow with adds and carries
+  const unsigned dstep = 32u * (unsigned)tstride;
+  const int d_n = (int)(dstep / (unsigned)HoWo);
+  const int d_r = (int)(dstep - (unsigned)d_n * (unsigned)HoWo);
+  const int d_ho = d_r / a.Wo, d_wo = d_r - d_ho * a.Wo;
+  const bool acc_in = a.accumulate != 0, fin = a.final_pass != 0;
+  const bool want_pre = fin && a.res_pre, want_post = fin && a.res_post, relu = fin && a.relu;
+  const int ob = 4 * hh;                         // the lane's out-channel of register i: ob + (i & 3) + 8 (i >> 2)
 
   struct Pix {
-    int n, r, ho, wo;
+    int n, ho, wo;
   };
-  auto decode = [&](int tile) {
-    const unsigned p = (unsigned)min((long long)tile * 32 + col, total - 1);
-    Pix px;
-    px.n = (int)(p / (unsigned)HoWo);
-    px.r = (int)(p - (unsigned)px.n * (unsigned)HoWo);
-    px.ho = (int)((unsigned)px.r / (unsigned)a.Wo);
-    px.wo = px.r - px.ho * a.Wo;
-    return px;
+  auto advance = [&](Pix& px) {
+    px.wo += d_wo;
+    px.ho += d_ho;
+    px.n += d_n;
+    if (px.wo >= a.Wo) {
+      px.wo -= a.Wo;
+      px.ho += 1;
+    }
+    if (px.ho >= a.Ho) {
+      px.ho -= a.Ho;
+      px.n += 1;
+    }
   };
   auto request = [&](const Pix& px, unsigned (&x)[NW]) {
-    // dword index of (word, half) = 2 * word + hh; words: [plane][n][GG][Hp][Wp]
-    const unsigned base = 2u * (unsigned)((px.n * GG * a.Hp + px.ho * a.sh) * a.Wp + px.wo * a.sw) + (unsigned)hh;
+    // dword index of (word, half) = 2 * word + hh; words: [plane][n][GG][Hp][Wp]; lanes past the last pixel (last tile
+    // only) read the words of image 0 and store nothing
+    const int n = px.n < a.N ? px.n : 0;
+    const unsigned base = 2u * (unsigned)((n * GG * a.Hp + px.ho * a.sh) * a.Wp + px.wo * a.sw) + (unsigned)hh;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -112,7 +131,14 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
 
   int tile = blockIdx.x * 4 + wid;
   if (tile >= ntiles) return;
-  Pix cur = decode(tile);
+  Pix cur;
+  {
+    const unsigned p = (unsigned)tile * 32u + (unsigned)col;
+    cur.n = (int)(p / (unsigned)HoWo);
+    const int r = (int)(p - (unsigned)cur.n * (unsigned)HoWo);
+    cur.ho = (int)((unsigned)r / (unsigned)a.Wo);
+    cur.wo = r - cur.ho * a.Wo;
+  }
   unsigned xc[NW];
   request(cur, xc);
   for (;;) {
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
     Pix nx = cur;
     unsigned xn[NW];
     if (more) {
-      nx = decode(nxt);
+      advance(nx);
       request(nx, xn);
     }
 
@@ -150,72 +176,64 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
     }
 
     // ---- epilogue of this tile: the popcount kernel's arithmetic on the same integers -> the same floats --------
-    const bool pvalid = (long long)tile * 32 + col < total;
-    int corr[16];
+    if (cur.n < a.N) {                           // (false only for the lanes past the last pixel)
+      const int hi0 = cur.ho * a.sh - a.ph, wi0 = cur.wo * a.sw - a.pw;
+      unsigned bad_h = 0, bad_w = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) corr[i] = 0;
-    const int hi0 = cur.ho * a.sh - a.ph, wi0 = cur.wo * a.sw - a.pw;
-    unsigned bad_h = 0, bad_w = 0;
-    for (int kh = 0; kh < a.KH; ++kh) {
-      const int hi = hi0 + kh * a.dh;
-      bad_h |= (hi < 0 || hi >= a.H) ? 1u << kh : 0u;
-    }
-    for (int kw = 0; kw < a.KW; ++kw) {
-      const int wi = wi0 + kw * a.dw;
-      bad_w |= (wi < 0 || wi >= a.W) ? 1u << kw : 0u;
-    }
-    const int ob = 4 * hh;                       // the lane's out-channel of register i: ob + (i & 3) + 8 (i >> 2)
-    if (bad_h | bad_w) {
-      for (int kh = 0; kh < a.KH; ++kh) {
-        if ((bad_h >> kh) & 1u) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) corr[i] += s_rs[kh][ob + (i & 3) + 8 * (i >> 2)];
-          for (int kw = 0; kw < a.KW; ++kw) {
-            if ((bad_w >> kw) & 1u) {
-#pragma unroll
-              for (int i = 0; i < 16; ++i) corr[i] -= s_ws[kh * a.KW + kw][ob + (i & 3) + 8 * (i >> 2)];
-            }
-          }
-        }
+      for (int k = 0; k < 3; ++k) {
+        const int hi = hi0 + k * a.dh, wi = wi0 + k * a.dw;
+        bad_h |= (hi < 0 || hi >= a.H) ? 1u << k : 0u;
+        bad_w |= (wi < 0 || wi >= a.W) ? 1u << k : 0u;
       }
-      for (int kw = 0; kw < a.KW; ++kw) {
-        if ((bad_w >> kw) & 1u) {
+      const int* __restrict__ fcp = &s_fc[bad_h][bad_w][ob];
+      int4 fcv[4];
+      float4 scv[4], bsv[4];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) corr[i] += s_cs[kw][ob + (i & 3) + 8 * (i >> 2)];
-        }
+      for (int g = 0; g < 4; ++g) {
+        fcv[g] = *reinterpret_cast<const int4*>(fcp + 8 * g);
+        scv[g] = *reinterpret_cast<const float4*>(&s_scale[ob + 8 * g]);
+        bsv[g] = *reinterpret_cast<const float4*>(&s_bias[ob + 8 * g]);
       }
-    }
-    if (pvalid) {
       float xs[KX];
 #pragma unroll
-      for (int p = 0; p < KX; ++p) xs[p] = a.xscales[(long long)p * a.N + cur.n];
-      const long long ybase = ((long long)cur.n * a.O + o0 + ob) * HoWo + cur.r;
-      float* __restrict__ yp = a.y + ybase;
-      const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
-      const float* rsrc = (want_pre ? a.res_pre : a.res_post) + ybase;
-      float rv[16], basev[16], wsv[16];
+      for (int p = 0; p < KX; ++p) xs[p] = a.xscales[p * a.N + cur.n];
+      // 32-bit element offsets from uniform bases (the entry point admits outputs below 2^30 elements)
+      const unsigned yoff = (unsigned)((cur.n * a.O + o0 + ob) * HoWo + cur.ho * a.Wo + cur.wo);
+      float rv[16], basev[16];
+      if (want_pre || want_post) {
+        const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int oo = (i & 3) + 8 * (i >> 2);
-        rv[i] = (want_pre || want_post) ? rsrc[(long long)oo * HoWo] : 0.f;
-        basev[i] = a.accumulate ? yp[(long long)oo * HoWo] : (a.bias ? a.bias[o0 + ob + oo] : 0.f);
-        wsv[i] = a.wscale[o0 + ob + oo];
+        for (int i = 0; i < 16; ++i) rv[i] = (rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[i] = 0.f;
       }
+      if (acc_in) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) basev[i] = (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) basev[i] = reinterpret_cast<const float*>(&bsv[i >> 2])[i & 3];
+      }
+      float outv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int oo = (i & 3) + 8 * (i >> 2);
-        const int fc = corr[i] - s_tot[ob + oo];
+        const int fc = reinterpret_cast<const int*>(&fcv[i >> 2])[i & 3];
         float v = xs[0] * (float)(fc + (acc[0][i] >> 5));
 #pragma unroll
         for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)(fc + (acc[p][i] >> 5)), v);
-        float out = fmaf(v, wsv[i], basev[i]);
-        if (a.final_pass) {
-          if (want_pre) out += rv[i];
-          if (a.relu) out = fmaxf(out, 0.f);
-          if (want_post) out += want_pre ? a.res_post[ybase + (long long)oo * HoWo] : rv[i];
-        }
-        yp[(long long)oo * HoWo] = out;
+        float out = fmaf(v, reinterpret_cast<const float*>(&scv[i >> 2])[i & 3], basev[i]);
+        if (want_pre) out += rv[i];
+        if (relu) out = fmaxf(out, 0.f);
+        if (want_post && !want_pre) out += rv[i];
+        outv[i] = out;
       }
+      if (want_post && want_pre) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) outv[i] += (a.res_post + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff] = outv[i];
     }
 
     if (!more) break;
@@ -243,7 +261,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 int xnor_conv_mfma(const ConvArgs& a, int kx, int groups, hipStream_t st) {
   const long long total = (long long)a.N * a.Ho * a.Wo;
-  if (groups != 1 || a.cg != 64 || a.KH != 3 || a.KW != 3 || a.O % 32 || total >= (1ll << 31) - 64 ||
+  if (groups != 1 || a.cg != 64 || a.KH != 3 || a.KW != 3 || a.O % 32 || total * a.O >= (1ll << 30) ||
       a.xplane_words * kx >= (1ll << 30))
     return kXnorMfmaNotEligible;
   return kx == 2 ? launch<2>(a, st) : launch<1>(a, st);
