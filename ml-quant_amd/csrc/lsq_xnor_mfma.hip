@@ -34,26 +34,32 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr unsigned kM0 = 0x01010101u;
 
-template <int KX, int GG, int TAPS>
-__global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
-  constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (tap, word, half of the dword's bits)
-  constexpr int NW = TAPS * GG * KX;             // activation dwords per lane and tile
+// WREG: the weight fragments live in registers (GG = 1: 72 VGPRs); otherwise they are re-read from LDS for every
+// tile (conflict-free ds_read_b128, a quarter to a half of the LDS bandwidth at full MFMA rate).
+// NWAVES: waves per workgroup, all on the same 32 out-channels (8 when the fragments of 512 channels fill the LDS of
+// a CU: one workgroup per CU, still two waves per SIMD).
+template <int KX, int GG, int TAPS, bool WREG, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(ConvArgs a) {
+  constexpr int NT = 64 * NWAVES;
+  constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (word, tap, half of the dword's bits)
+  constexpr int NW = TAPS * KX;                  // activation dwords per lane and group (= one channel word of a tile)
   __shared__ v4i s_w[NF][64];
   __shared__ int s_ws[TAPS][32];
   // fc[bad rows][bad columns][o] = sum of wsum over the taps OUTSIDE the image - sum over all taps: what a pixel
   // with that border pattern adds to 2 * (matrix-core sum).  3 x 3 taps: 8 x 8 patterns, one table look-up per
   // output instead of loops over kernel rows and columns.
-  __shared__ __attribute__((aligned(16))) int s_fc[8][8][32];
+  __shared__ __attribute__((aligned(16))) short s_fc[8][8][32];    // |.| <= taps * channels = 4608
   __shared__ __attribute__((aligned(16))) float s_scale[32], s_bias[32];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int o0 = blockIdx.y * 32;
 
   // ---- once per workgroup: weight fragments and epilogue tables of its 32 out-channels ----------------------------
-  for (int e = tid; e < NF * 256; e += 256) {
+  for (int e = tid; e < NF * 256; e += NT) {
     const int r = e & 3, L = (e >> 2) & 63, f = e >> 8;
     const int q = 4 * (f & 1) + r;
-    const unsigned long long w = a.wbits[(long long)(f >> 1) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
+    const int fj = (f >> 1) / TAPS, ft = (f >> 1) - fj * TAPS;                                  // fragment order: word-major
+    const unsigned long long w = a.wbits[(long long)(ft * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
     const unsigned d = (L >> 5) ? (unsigned)(w >> 32) : (unsigned)w;
     const int mag = q < 7 ? (64 >> q) : 64;
     unsigned out = 0;
@@ -61,13 +67,13 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
     for (int b = 0; b < 4; ++b) out |= (unsigned)(((d >> (q + 8 * b)) & 1u ? mag : -mag) & 0xFF) << (8 * b);
     reinterpret_cast<unsigned*>(&s_w[f][L])[r] = out;
   }
-  for (int i = tid; i < TAPS * 32; i += 256) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
+  for (int i = tid; i < TAPS * 32; i += NT) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
   if (tid < 32) {
     s_scale[tid] = a.wscale[o0 + tid];
     s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < 8 * 8 * 32; i += 256) {
+  for (int i = tid; i < 8 * 8 * 32; i += NT) {
     const int o = i & 31, bw = (i >> 5) & 7, bh = i >> 8;
     int v = 0;
 #pragma unroll
@@ -75,21 +81,22 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
       const bool outside = ((bh >> (tp / 3)) & 1) | ((bw >> (tp % 3)) & 1);
       v -= outside ? 0 : s_ws[tp][o];
     }
-    s_fc[bh][bw][o] = v;
+    s_fc[bh][bw][o] = (short)v;
   }
   __syncthreads();
-  v4i wreg[NF];
+  v4i wreg[WREG ? NF : 1];
+  if (WREG) {
 #pragma unroll
-  for (int f = 0; f < NF; ++f) wreg[f] = s_w[f][lane];
+    for (int f = 0; f < NF; ++f) wreg[f] = s_w[f][lane];
+  }
 
   // ---- tiles ------------------------------------------------------------------------------------------------------
   const unsigned total = (unsigned)(a.N * a.Ho * a.Wo);
   const int ntiles = (int)((total + 31u) >> 5);
   const int HoWo = a.Ho * a.Wo;
-  const int HpWp = a.Hp * a.Wp;
   const unsigned* __restrict__ xd = reinterpret_cast<const unsigned*>(a.xplanes);
   const unsigned plane_stride = 2u * (unsigned)a.xplane_words;
-  const int tstride = gridDim.x * 4;
+  const int tstride = gridDim.x * NWAVES;
   // a wave's pixel index advances by the same amount from tile to tile: (n, ho, wo) follow with adds and carries
   const unsigned dstep = 32u * (unsigned)tstride;
   const int d_n = (int)(dstep / (unsigned)HoWo);
@@ -115,21 +122,18 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
       px.n += 1;
     }
   };
-  auto request = [&](const Pix& px, unsigned (&x)[NW]) {
+  auto request = [&](const Pix& px, int j, unsigned (&x)[NW]) {
     // dword index of (word, half) = 2 * word + hh; words: [plane][n][GG][Hp][Wp]; lanes past the last pixel (last tile
     // only) read the words of image 0 and store nothing
     const int n = px.n < a.N ? px.n : 0;
-    const unsigned base = 2u * (unsigned)((n * GG * a.Hp + px.ho * a.sh) * a.Wp + px.wo * a.sw) + (unsigned)hh;
+    const unsigned base = 2u * (unsigned)(((n * GG + j) * a.Hp + px.ho * a.sh) * a.Wp + px.wo * a.sw) + (unsigned)hh;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int j = 0; j < GG; ++j)
-#pragma unroll
-        for (int p = 0; p < KX; ++p)
-          x[(t * GG + j) * KX + p] = xd[base + 2u * (unsigned)(a.tap_xoff[t] + j * HpWp) + (unsigned)p * plane_stride];
+      for (int p = 0; p < KX; ++p) x[t * KX + p] = xd[base + 2u * (unsigned)a.tap_xoff[t] + (unsigned)p * plane_stride];
   };
 
-  int tile = blockIdx.x * 4 + wid;
+  int tile = blockIdx.x * NWAVES + wid;
   if (tile >= ntiles) return;
   Pix cur;
   {
@@ -140,38 +144,51 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
     cur.wo = r - cur.ho * a.Wo;
   }
   unsigned xc[NW];
-  request(cur, xc);
+  request(cur, 0, xc);
   for (;;) {
     const int nxt = tile + tstride;
     const bool more = nxt < ntiles;
     Pix nx = cur;
-    unsigned xn[NW];
-    if (more) {
-      advance(nx);
-      request(nx, xn);
-    }
+    if (more) advance(nx);
 
     v16i acc[KX];
 #pragma unroll
     for (int p = 0; p < KX; ++p)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[p][i] = 0;
+    // groups = channel words; the words of the next group (the next word of this tile, or the first word of the
+    // wave's next tile) are requested before this group's MFMAs
+    int wl = lane;                               // opaque per tile: the fragment reads must not be hoisted out of
+    asm volatile("" : "+v"(wl));                 // the tile loop (36 fragments = 144 VGPRs)
 #pragma unroll
-    for (int tj = 0; tj < TAPS * GG; ++tj) {
+    for (int j = 0; j < GG; ++j) {
+      unsigned xn[NW];
+      if (j + 1 < GG) request(cur, j + 1, xn);
+      else if (more) request(nx, 0, xn);
 #pragma unroll
-      for (int p = 0; p < KX; ++p) {
-        const unsigned d = xc[tj * KX + p];
-        v4i b0, b1;
-        b0[0] = (int)(d & kM0);
-        b0[1] = (int)(d & (kM0 << 1));
-        b0[2] = (int)(d & (kM0 << 2));
-        b0[3] = (int)(d & (kM0 << 3));
-        b1[0] = (int)(d & (kM0 << 4));
-        b1[1] = (int)(d & (kM0 << 5));
-        b1[2] = (int)(d & (kM0 << 6));
-        b1[3] = (int)((d >> 7) & kM0);
-        acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wreg[2 * tj], b0, acc[p], 0, 0, 0);
-        acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wreg[2 * tj + 1], b1, acc[p], 0, 0, 0);
+      for (int t = 0; t < TAPS; ++t) {
+        const int f = (j * TAPS + t) * 2;
+        const v4i w0 = WREG ? wreg[WREG ? f : 0] : s_w[f][wl];
+        const v4i w1 = WREG ? wreg[WREG ? f + 1 : 0] : s_w[f + 1][wl];
+#pragma unroll
+        for (int p = 0; p < KX; ++p) {
+          const unsigned d = xc[t * KX + p];
+          v4i b0, b1;
+          b0[0] = (int)(d & kM0);
+          b0[1] = (int)(d & (kM0 << 1));
+          b0[2] = (int)(d & (kM0 << 2));
+          b0[3] = (int)(d & (kM0 << 3));
+          b1[0] = (int)(d & (kM0 << 4));
+          b1[1] = (int)(d & (kM0 << 5));
+          b1[2] = (int)(d & (kM0 << 6));
+          b1[3] = (int)((d >> 7) & kM0);
+          acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1, acc[p], 0, 0, 0);
+        }
+      }
+      if (j + 1 < GG || more) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) xc[i] = xn[i];
       }
     }
 
@@ -185,12 +202,12 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
         bad_h |= (hi < 0 || hi >= a.H) ? 1u << k : 0u;
         bad_w |= (wi < 0 || wi >= a.W) ? 1u << k : 0u;
       }
-      const int* __restrict__ fcp = &s_fc[bad_h][bad_w][ob];
-      int4 fcv[4];
+      const short* __restrict__ fcp = &s_fc[bad_h][bad_w][ob];
+      short4 fcv[4];
       float4 scv[4], bsv[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        fcv[g] = *reinterpret_cast<const int4*>(fcp + 8 * g);
+        fcv[g] = *reinterpret_cast<const short4*>(fcp + 8 * g);
         scv[g] = *reinterpret_cast<const float4*>(&s_scale[ob + 8 * g]);
         bsv[g] = *reinterpret_cast<const float4*>(&s_bias[ob + 8 * g]);
       }
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
       float outv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int fc = reinterpret_cast<const int*>(&fcv[i >> 2])[i & 3];
+        const int fc = reinterpret_cast<const short*>(&fcv[i >> 2])[i & 3];
         float v = xs[0] * (float)(fc + (acc[0][i] >> 5));
 #pragma unroll
         for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)(fc + (acc[p][i] >> 5)), v);
@@ -239,32 +256,42 @@ __global__ __launch_bounds__(256, 2) void xnor_mfma_kernel(ConvArgs a) {
     if (!more) break;
     tile = nxt;
     cur = nx;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) xc[i] = xn[i];
   }
 }
 
-template <int KX>
+template <int KX, int GG>
 int launch(const ConvArgs& a, hipStream_t st) {
+  constexpr int NWAVES = GG >= 8 ? 8 : 4;
   const long long total = (long long)a.N * a.Ho * a.Wo;
   const long long ntiles = (total + 31) >> 5;
   const int n_ot = a.O / 32;
-  // two workgroups per CU, each wave strides over the tiles of its out-channel tile
-  long long gx = (512 + n_ot - 1) / n_ot;
+  // eight waves per CU in all, each wave strides over the pixel tiles of its workgroup's out-channel tile
+  const int wgs = 256 * 8 / NWAVES;
+  long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
-  if (gx * 4 > ntiles) gx = (ntiles + 3) / 4;
-  hipLaunchKernelGGL((xnor_mfma_kernel<KX, 1, 9>), dim3((unsigned)gx, (unsigned)n_ot), dim3(256), 0, st, a);
+  if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
+  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, GG == 1, NWAVES>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
+}
+
+template <int KX>
+int launch_gg(const ConvArgs& a, hipStream_t st) {
+  switch (a.cg) {
+    case 64: return launch<KX, 1>(a, st);
+    case 128: return launch<KX, 2>(a, st);
+    case 256: return launch<KX, 4>(a, st);
+    case 512: return launch<KX, 8>(a, st);
+  }
+  return kXnorMfmaNotEligible;
 }
 
 }  // namespace
 
 int xnor_conv_mfma(const ConvArgs& a, int kx, int groups, hipStream_t st) {
   const long long total = (long long)a.N * a.Ho * a.Wo;
-  if (groups != 1 || a.cg != 64 || a.KH != 3 || a.KW != 3 || a.O % 32 || total * a.O >= (1ll << 30) ||
-      a.xplane_words * kx >= (1ll << 30))
+  if (groups != 1 || a.KH != 3 || a.KW != 3 || a.O % 32 || total * a.O >= (1ll << 30) || a.xplane_words * kx >= (1ll << 30))
     return kXnorMfmaNotEligible;
-  return kx == 2 ? launch<2>(a, st) : launch<1>(a, st);
+  return kx == 2 ? launch_gg<2>(a, st) : launch_gg<1>(a, st);
 }
 
 }  // namespace lsq
