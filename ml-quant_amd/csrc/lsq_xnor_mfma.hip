@@ -55,17 +55,24 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
   const int o0 = blockIdx.y * 32;
 
   // ---- once per workgroup: weight fragments and epilogue tables of its 32 out-channels ----------------------------
-  for (int e = tid; e < NF * 256; e += NT) {
-    const int r = e & 3, L = (e >> 2) & 63, f = e >> 8;
-    const int q = 4 * (f & 1) + r;
-    const int fj = (f >> 1) / TAPS, ft = (f >> 1) - fj * TAPS;                                  // fragment order: word-major
+  // one thread = one (fragment pair, lane) entry: the weight word's dword of the lane's half, eight registers of four
+  // bytes +-(64 >> q): bytes (d >> q) & 0x01010101 -> 0x00 / 0xFF masks -> select between the two byte patterns
+  for (int e = tid; e < TAPS * GG * 64; e += NT) {
+    const int L = e & 63, tj = e >> 6;
+    const int fj = tj / TAPS, ft = tj - fj * TAPS;                                               // fragment order: word-major
     const unsigned long long w = a.wbits[(long long)(ft * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
     const unsigned d = (L >> 5) ? (unsigned)(w >> 32) : (unsigned)w;
-    const int mag = q < 7 ? (64 >> q) : 64;
-    unsigned out = 0;
+    v4i out[2];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) out |= (unsigned)(((d >> (q + 8 * b)) & 1u ? mag : -mag) & 0xFF) << (8 * b);
-    reinterpret_cast<unsigned*>(&s_w[f][L])[r] = out;
+    for (int q = 0; q < 8; ++q) {
+      const unsigned mag = q < 7 ? (64u >> q) : 64u;
+      const unsigned pos = mag * kM0, neg = ((256u - mag) & 0xFFu) * kM0;
+      const unsigned ones = (d >> q) & kM0;
+      const unsigned mask = (ones << 8) - ones;                                                  // 0xFF where the bit is set
+      out[q >> 2][q & 3] = (int)(neg ^ ((pos ^ neg) & mask));
+    }
+    s_w[2 * tj][L] = out[0];
+    s_w[2 * tj + 1][L] = out[1];
   }
   for (int i = tid; i < TAPS * 32; i += NT) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
   if (tid < 32) {
@@ -145,6 +152,14 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
   }
   unsigned xc[NW];
   request(cur, 0, xc);
+  v4i wring[3][2];                               // weight fragments of three consecutive (word, tap) steps
+  if (!WREG) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wring[i][0] = s_w[2 * i][lane];
+      wring[i][1] = s_w[2 * i + 1][lane];
+    }
+  }
   for (;;) {
     const int nxt = tile + tstride;
     const bool more = nxt < ntiles;
@@ -158,33 +173,48 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
       for (int i = 0; i < 16; ++i) acc[p][i] = 0;
     // groups = channel words; the words of the next group (the next word of this tile, or the first word of the
     // wave's next tile) are requested before this group's MFMAs
+    // Order of issue, enforced with scheduling barriers (left alone, the compiler sinks the prefetches to a few
+    // instructions before their use): the words of the NEXT group first -- the next channel word of this tile, or
+    // the first word of the wave's next tile: a whole group of 36 MFMAs ahead --, then per tap the weight fragments
+    // of the tap after the next (a ring of three, wrapping around into the next tile: the fragments are the same
+    // for every tile), then this tap's 18 v_and and 4 MFMAs.
     int wl = lane;                               // opaque per tile: the fragment reads must not be hoisted out of
-    asm volatile("" : "+v"(wl));                 // the tile loop (36 fragments = 144 VGPRs)
+    asm volatile("" : "+v"(wl));                 // the tile loop (36 and more fragments)
 #pragma unroll
     for (int j = 0; j < GG; ++j) {
       unsigned xn[NW];
       if (j + 1 < GG) request(cur, j + 1, xn);
       else if (more) request(nx, 0, xn);
+      if (!WREG) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
-        const int f = (j * TAPS + t) * 2;
-        const v4i w0 = WREG ? wreg[WREG ? f : 0] : s_w[f][wl];
-        const v4i w1 = WREG ? wreg[WREG ? f + 1 : 0] : s_w[f + 1][wl];
+        constexpr int kAll = GG * TAPS;
+        const int idx = j * TAPS + t;
+        if (!WREG) {
+          const int pre = (idx + 2) % kAll;
+          wring[(idx + 2) % 3][0] = s_w[2 * pre][wl];
+          wring[(idx + 2) % 3][1] = s_w[2 * pre + 1][wl];
+        }
+        const v4i w0 = WREG ? wreg[WREG ? 2 * idx : 0] : wring[idx % 3][0];
+        const v4i w1 = WREG ? wreg[WREG ? 2 * idx + 1 : 0] : wring[idx % 3][1];
+        v4i b0[KX], b1[KX];
 #pragma unroll
         for (int p = 0; p < KX; ++p) {
           const unsigned d = xc[t * KX + p];
-          v4i b0, b1;
-          b0[0] = (int)(d & kM0);
-          b0[1] = (int)(d & (kM0 << 1));
-          b0[2] = (int)(d & (kM0 << 2));
-          b0[3] = (int)(d & (kM0 << 3));
-          b1[0] = (int)(d & (kM0 << 4));
-          b1[1] = (int)(d & (kM0 << 5));
-          b1[2] = (int)(d & (kM0 << 6));
-          b1[3] = (int)((d >> 7) & kM0);
-          acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0, acc[p], 0, 0, 0);
-          acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1, acc[p], 0, 0, 0);
+          b0[p][0] = (int)(d & kM0);
+          b0[p][1] = (int)(d & (kM0 << 1));
+          b0[p][2] = (int)(d & (kM0 << 2));
+          b0[p][3] = (int)(d & (kM0 << 3));
+          b1[p][0] = (int)(d & (kM0 << 4));
+          b1[p][1] = (int)(d & (kM0 << 5));
+          b1[p][2] = (int)(d & (kM0 << 6));
+          b1[p][3] = (int)((d >> 7) & kM0);
         }
+#pragma unroll
+        for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0[p], acc[p], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1[p], acc[p], 0, 0, 0);
+        if (!WREG) __builtin_amdgcn_sched_barrier(0);
       }
       if (j + 1 < GG || more) {
 #pragma unroll
