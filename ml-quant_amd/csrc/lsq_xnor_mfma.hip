@@ -140,7 +140,9 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
       for (int p = 0; p < KX; ++p) x[t * KX + p] = xd[base + 2u * (unsigned)a.tap_xoff[t] + (unsigned)p * plane_stride];
   };
 
-  int tile = blockIdx.x * NWAVES + wid;
+  // wave-major numbering: when the tiles do not divide evenly, the waves with one tile more sit in different
+  // workgroups (on different SIMDs) instead of filling one
+  int tile = wid * gridDim.x + blockIdx.x;
   if (tile >= ntiles) return;
   Pix cur;
   {
@@ -152,10 +154,11 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
   }
   unsigned xc[NW];
   request(cur, 0, xc);
-  v4i wring[3][2];                               // weight fragments of three consecutive (word, tap) steps
+  constexpr int kRing = 3;                       // weight fragments of kRing consecutive (word, tap) steps; 9 GG % kRing == 0
+  v4i wring[kRing][2];
   if (!WREG) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kRing - 1; ++i) {
       wring[i][0] = s_w[2 * i][lane];
       wring[i][1] = s_w[2 * i + 1][lane];
     }
@@ -166,13 +169,37 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
     Pix nx = cur;
     if (more) advance(nx);
 
+    // What the epilogue reads from memory is requested NOW, a whole tile of MFMAs ahead: the two waves of a SIMD run
+    // in lockstep (same start, same tile length), so a load waited for in the epilogue stalls the matrix core for
+    // its full latency -- that, not the MFMA rate, set the pace of the first version.
+    const int ln = cur.n < a.N ? cur.n : 0;
+    // 32-bit element offsets from uniform bases (the entry point admits outputs below 2^30 elements)
+    const unsigned yoff = (unsigned)((ln * a.O + o0 + ob) * HoWo + cur.ho * a.Wo + cur.wo);
+    float xs[KX], rv[16], basev[16];
+#pragma unroll
+    for (int p = 0; p < KX; ++p) xs[p] = a.xscales[p * a.N + ln];
+    if (want_pre || want_post) {
+      const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rv[i] = (rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+    }
+    if (acc_in) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) basev[i] = (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) basev[i] = s_bias[ob + (i & 3) + 8 * (i >> 2)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     v16i acc[KX];
 #pragma unroll
     for (int p = 0; p < KX; ++p)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[p][i] = 0;
-    // groups = channel words; the words of the next group (the next word of this tile, or the first word of the
-    // wave's next tile) are requested before this group's MFMAs
     // Order of issue, enforced with scheduling barriers (left alone, the compiler sinks the prefetches to a few
     // instructions before their use): the words of the NEXT group first -- the next channel word of this tile, or
     // the first word of the wave's next tile: a whole group of 36 MFMAs ahead --, then per tap the weight fragments
@@ -191,12 +218,13 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
         constexpr int kAll = GG * TAPS;
         const int idx = j * TAPS + t;
         if (!WREG) {
-          const int pre = (idx + 2) % kAll;
-          wring[(idx + 2) % 3][0] = s_w[2 * pre][wl];
-          wring[(idx + 2) % 3][1] = s_w[2 * pre + 1][wl];
+          const int pre = (idx + kRing - 1) % kAll;
+          wring[(idx + kRing - 1) % kRing][0] = s_w[2 * pre][wl];
+          wring[(idx + kRing - 1) % kRing][1] = s_w[2 * pre + 1][wl];
+          __builtin_amdgcn_sched_barrier(0);       // reads first: they must not sink below this step's MFMAs
         }
-        const v4i w0 = WREG ? wreg[WREG ? 2 * idx : 0] : wring[idx % 3][0];
-        const v4i w1 = WREG ? wreg[WREG ? 2 * idx + 1 : 0] : wring[idx % 3][1];
+        const v4i w0 = WREG ? wreg[WREG ? 2 * idx : 0] : wring[idx % kRing][0];
+        const v4i w1 = WREG ? wreg[WREG ? 2 * idx + 1 : 0] : wring[idx % kRing][1];
         v4i b0[KX], b1[KX];
 #pragma unroll
         for (int p = 0; p < KX; ++p) {
@@ -234,33 +262,11 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
       }
       const short* __restrict__ fcp = &s_fc[bad_h][bad_w][ob];
       short4 fcv[4];
-      float4 scv[4], bsv[4];
+      float4 scv[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         fcv[g] = *reinterpret_cast<const short4*>(fcp + 8 * g);
         scv[g] = *reinterpret_cast<const float4*>(&s_scale[ob + 8 * g]);
-        bsv[g] = *reinterpret_cast<const float4*>(&s_bias[ob + 8 * g]);
-      }
-      float xs[KX];
-#pragma unroll
-      for (int p = 0; p < KX; ++p) xs[p] = a.xscales[p * a.N + cur.n];
-      // 32-bit element offsets from uniform bases (the entry point admits outputs below 2^30 elements)
-      const unsigned yoff = (unsigned)((cur.n * a.O + o0 + ob) * HoWo + cur.ho * a.Wo + cur.wo);
-      float rv[16], basev[16];
-      if (want_pre || want_post) {
-        const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = (rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = 0.f;
-      }
-      if (acc_in) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) basev[i] = (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) basev[i] = reinterpret_cast<const float*>(&bsv[i >> 2])[i & 3];
       }
       float outv[16];
 #pragma unroll
@@ -269,11 +275,19 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
         float v = xs[0] * (float)(fc + (acc[0][i] >> 5));
 #pragma unroll
         for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)(fc + (acc[p][i] >> 5)), v);
-        float out = fmaf(v, reinterpret_cast<const float*>(&scv[i >> 2])[i & 3], basev[i]);
-        if (want_pre) out += rv[i];
-        if (relu) out = fmaxf(out, 0.f);
-        if (want_post && !want_pre) out += rv[i];
-        outv[i] = out;
+        outv[i] = fmaf(v, reinterpret_cast<const float*>(&scv[i >> 2])[i & 3], basev[i]);
+      }
+      if (want_pre) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) outv[i] += rv[i];
+      }
+      if (relu) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) outv[i] = fmaxf(outv[i], 0.f);
+      }
+      if (want_post && !want_pre) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) outv[i] += rv[i];
       }
       if (want_post && want_pre) {
 #pragma unroll
@@ -300,7 +314,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
   long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
   if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
-  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, GG == 1, NWAVES>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, false, NWAVES>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
 }
 
