@@ -38,8 +38,8 @@ constexpr unsigned kM0 = 0x01010101u;
 // tile (conflict-free ds_read_b128, a quarter to a half of the LDS bandwidth at full MFMA rate).
 // NWAVES: waves per workgroup, all on the same 32 out-channels (8 when the fragments of 512 channels fill the LDS of
 // a CU: one workgroup per CU, still two waves per SIMD).
-template <int KX, int GG, int TAPS, bool WREG, int NWAVES>
-__global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(ConvArgs a) {
+template <int KX, int GG, int TAPS, bool WREG, int NWAVES, int WPC>
+__global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
   constexpr int NT = 64 * NWAVES;
   constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (word, tap, half of the dword's bits)
   constexpr int NW = TAPS * KX;                  // activation dwords per lane and group (= one channel word of a tile)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
     const unsigned yoff = (unsigned)((ln * a.O + o0 + ob) * HoWo + cur.ho * a.Wo + cur.wo);
     float xs[KX], rv[16], basev[16];
 #pragma unroll
-    for (int p = 0; p < KX; ++p) xs[p] = a.xscales[p * a.N + ln];
+    for (int p = 0; p < KX; ++p) xs[p] = a.xscales[p * a.N + ln] * 0.03125f;
     if (want_pre || want_post) {
       const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
 #pragma unroll
@@ -195,11 +195,31 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    // The accumulators start at 32 * fc (fc = what the pixel's border pattern adds to 2 * the matrix-core sum, from
+    // the table): the matrix core does the epilogue's integer additions, and 64 * S + 32 * fc = 32 * (b * s).
     v16i acc[KX];
+    {
+      const int hi0 = cur.ho * a.sh - a.ph, wi0 = cur.wo * a.sw - a.pw;
+      unsigned bad_h = 0, bad_w = 0;
 #pragma unroll
-    for (int p = 0; p < KX; ++p)
+      for (int k = 0; k < 3; ++k) {
+        const int hi = hi0 + k * a.dh, wi = wi0 + k * a.dw;
+        bad_h |= (hi < 0 || hi >= a.H) ? 1u << k : 0u;
+        bad_w |= (wi < 0 || wi >= a.W) ? 1u << k : 0u;
+      }
+      const short* __restrict__ fcp = &s_fc[bad_h][bad_w][ob];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[p][i] = 0;
+      for (int g = 0; g < 4; ++g) {
+        const short4 f4 = *reinterpret_cast<const short4*>(fcp + 8 * g);
+#pragma unroll
+        for (int p = 0; p < KX; ++p) {
+          acc[p][4 * g + 0] = (int)f4.x << 5;
+          acc[p][4 * g + 1] = (int)f4.y << 5;
+          acc[p][4 * g + 2] = (int)f4.z << 5;
+          acc[p][4 * g + 3] = (int)f4.w << 5;
+        }
+      }
+    }
     // Order of issue, enforced with scheduling barriers (left alone, the compiler sinks the prefetches to a few
     // instructions before their use): the words of the NEXT group first -- the next channel word of this tile, or
     // the first word of the wave's next tile: a whole group of 36 MFMAs ahead --, then per tap the weight fragments
@@ -252,29 +272,17 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
 
     // ---- epilogue of this tile: the popcount kernel's arithmetic on the same integers -> the same floats --------
     if (cur.n < a.N) {                           // (false only for the lanes past the last pixel)
-      const int hi0 = cur.ho * a.sh - a.ph, wi0 = cur.wo * a.sw - a.pw;
-      unsigned bad_h = 0, bad_w = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int hi = hi0 + k * a.dh, wi = wi0 + k * a.dw;
-        bad_h |= (hi < 0 || hi >= a.H) ? 1u << k : 0u;
-        bad_w |= (wi < 0 || wi >= a.W) ? 1u << k : 0u;
-      }
-      const short* __restrict__ fcp = &s_fc[bad_h][bad_w][ob];
-      short4 fcv[4];
+      // float(acc) = 32 * (b * s) exactly (|.| < 2^18) and xs / 32 is exact, so (xs / 32) * float(acc) is the very
+      // product xs * float(b * s) of the popcount kernel
       float4 scv[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        fcv[g] = *reinterpret_cast<const short4*>(fcp + 8 * g);
-        scv[g] = *reinterpret_cast<const float4*>(&s_scale[ob + 8 * g]);
-      }
+      for (int g = 0; g < 4; ++g) scv[g] = *reinterpret_cast<const float4*>(&s_scale[ob + 8 * g]);
       float outv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int fc = reinterpret_cast<const short*>(&fcv[i >> 2])[i & 3];
-        float v = xs[0] * (float)(fc + (acc[0][i] >> 5));
+        float v = xs[0] * (float)acc[0][i];
 #pragma unroll
-        for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)(fc + (acc[p][i] >> 5)), v);
+        for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)acc[p][i], v);
         outv[i] = fmaf(v, reinterpret_cast<const float*>(&scv[i >> 2])[i & 3], basev[i]);
       }
       if (want_pre) {
@@ -306,15 +314,18 @@ __global__ __launch_bounds__(64 * NWAVES, 8 / NWAVES) void xnor_mfma_kernel(Conv
 template <int KX, int GG>
 int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int NWAVES = GG >= 8 ? 8 : 4;
+  // workgroups per CU: the weight fragments of 256 / 512 channels fill half / all of the LDS; below that three
+  // workgroups (168 VGPRs each) hide more of the epilogue's memory latency than two
+  constexpr int WPC = GG >= 8 ? 1 : GG >= 4 ? 2 : 3;
   const long long total = (long long)a.N * a.Ho * a.Wo;
   const long long ntiles = (total + 31) >> 5;
   const int n_ot = a.O / 32;
-  // eight waves per CU in all, each wave strides over the pixel tiles of its workgroup's out-channel tile
-  const int wgs = 256 * 8 / NWAVES;
+  // every resident wave strides over the pixel tiles of its workgroup's out-channel tile
+  const int wgs = 256 * WPC;
   long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
   if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
-  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, false, NWAVES>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, false, NWAVES, WPC>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
 }
 
