@@ -5,6 +5,18 @@ Same contract as the reference's ``quant/binary/optimal.py`` (``opt_v1`` :121-15
 computes it (``csrc/lsq_act_quant.hip``): prefix sums are carried in fp64 and a candidate's
 cost is evaluated in closed form from them, O(M log M) per row with no [N, K, M] temporary.
 CUDA tensors go to the HIP solver; this torch formulation serves CPU tensors and autograd.
+
+Where this (and the HIP solver, which computes the same thing) intentionally differs from the reference:
+  * exact cost ties -- integer-valued or heavily clamped rows, where several candidates have exactly the same
+    true cost -- are broken by (fp64 closed-form cost, smallest sorted position); the reference takes the first
+    argmin of fp32 costs over its zero-padded candidate list, so which of the tied candidates it returns depends
+    on fp32 rounding of its own norm / mean reductions.  Either answer has the same least-squares cost.
+  * the ternary extra candidate (half the row mean, optimal.py:147-152) is the fp64 mean rounded to fp32, up to one
+    ulp from the reference's fp32 ``matrix.mean() / 2``;
+  * a row with no candidate returns 0 where the reference raises (cannot happen for rows of three or more elements
+    that are not all equal).
+On continuous data the results match the reference's bit for bit in most rows and within 1e-3 relative in the
+rest (near-tied candidates, see DESIGN.md section 7); tests/test_oracle_golden.py::test_exact_solver_vs_reference.
 """
 
 from typing import Tuple
