@@ -130,6 +130,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 # ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 _timing = None
 _timing_only = None
+_timing_paused = False
 
 
 def enable_timing(on: bool = True, only: Optional[Sequence[str]] = None) -> None:
@@ -139,6 +140,12 @@ def enable_timing(on: bool = True, only: Optional[Sequence[str]] = None) -> None
     global _timing, _timing_only
     _timing = {} if on else None
     _timing_only = None if only is None else frozenset(only)
+
+
+def pause_timing(paused: bool = True) -> None:
+    """Keep the records but stop (resume) bracketing calls: a benchmark samples some of its timed steps."""
+    global _timing_paused
+    _timing_paused = bool(paused)
 
 
 def drain_timing():
@@ -157,7 +164,7 @@ class _Timed:
         self.name, self.nbytes = name, (nbytes, ops)
 
     def __enter__(self):
-        self.on = _timing is not None and (_timing_only is None or self.name in _timing_only)
+        self.on = _timing is not None and not _timing_paused and (_timing_only is None or self.name in _timing_only)
         if self.on:                       # (events record on the current stream of the current device: call inside _on)
             self.s = torch.cuda.Event(enable_timing=True)
             self.e = torch.cuda.Event(enable_timing=True)
