@@ -315,7 +315,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_step_min': group_ms[0], 'ms_per_step_median': group_ms[len(group_ms) // 2],
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'u64 popcount + f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'i8 mfma on sign bits (exact integers) + f32', 'data': 'synthetic',
             'config': {'workload': f'ResNet-18 ImageNet ls-1 weight / {args.act} activation, '
                                    f'synthetic 3x224x224, batch {args.batch} per GPU, random-init weights',
                        'global_batch': world * args.batch, 'parallelism': f'dp{world} (batch-sharded replicas, '
