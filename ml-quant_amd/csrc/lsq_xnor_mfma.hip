@@ -54,50 +54,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   const int col = lane & 31, hh = lane >> 5;
   const int o0 = blockIdx.y * 32;
 
-  // ---- once per workgroup: weight fragments and epilogue tables of its 32 out-channels ----------------------------
-  // one thread = one (fragment pair, lane) entry: the weight word's dword of the lane's half, eight registers of four
-  // bytes +-(64 >> q): bytes (d >> q) & 0x01010101 -> 0x00 / 0xFF masks -> select between the two byte patterns
-  for (int e = tid; e < TAPS * GG * 64; e += NT) {
-    const int L = e & 63, tj = e >> 6;
-    const int fj = tj / TAPS, ft = tj - fj * TAPS;                                               // fragment order: word-major
-    const unsigned long long w = a.wbits[(long long)(ft * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
-    const unsigned d = (L >> 5) ? (unsigned)(w >> 32) : (unsigned)w;
-    v4i out[2];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const unsigned mag = q < 7 ? (64u >> q) : 64u;
-      const unsigned pos = mag * kM0, neg = ((256u - mag) & 0xFFu) * kM0;
-      const unsigned ones = (d >> q) & kM0;
-      const unsigned mask = (ones << 8) - ones;                                                  // 0xFF where the bit is set
-      out[q >> 2][q & 3] = (int)(neg ^ ((pos ^ neg) & mask));
-    }
-    s_w[2 * tj][L] = out[0];
-    s_w[2 * tj + 1][L] = out[1];
-  }
-  for (int i = tid; i < TAPS * 32; i += NT) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
-  if (tid < 32) {
-    s_scale[tid] = a.wscale[o0 + tid];
-    s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
-  }
-  __syncthreads();
-  for (int i = tid; i < 8 * 8 * 32; i += NT) {
-    const int o = i & 31, bw = (i >> 5) & 7, bh = i >> 8;
-    int v = 0;
-#pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
-      const bool outside = ((bh >> (tp / 3)) & 1) | ((bw >> (tp % 3)) & 1);
-      v -= outside ? 0 : s_ws[tp][o];
-    }
-    s_fc[bh][bw][o] = (short)v;
-  }
-  __syncthreads();
-  v4i wreg[WREG ? NF : 1];
-  if (WREG) {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) wreg[f] = s_w[f][lane];
-  }
-
-  // ---- tiles ------------------------------------------------------------------------------------------------------
+  // ---- tile bookkeeping (before the tables: the first loads go out early) --------------------------------------
   const unsigned total = (unsigned)(a.N * a.Ho * a.Wo);
   const int ntiles = (int)((total + 31u) >> 5);
   const int HoWo = a.Ho * a.Wo;
@@ -143,7 +100,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   // wave-major numbering: when the tiles do not divide evenly, the waves with one tile more sit in different
   // workgroups (on different SIMDs) instead of filling one
   int tile = wid * gridDim.x + blockIdx.x;
-  if (tile >= ntiles) return;
+  const bool have_tile = tile < ntiles;
   Pix cur;
   {
     const unsigned p = (unsigned)tile * 32u + (unsigned)col;
@@ -152,8 +109,56 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     cur.ho = (int)((unsigned)r / (unsigned)a.Wo);
     cur.wo = r - cur.ho * a.Wo;
   }
+  // the first tile's words are requested before the workgroup builds its tables: their latency hides behind it
   unsigned xc[NW];
-  request(cur, 0, xc);
+  if (have_tile) request(cur, 0, xc);
+
+  // ---- once per workgroup: weight fragments and epilogue tables of its 32 out-channels ----------------------------
+  // one thread = one (fragment pair, lane) entry: the weight word's dword of the lane's half, eight registers of four
+  // bytes +-(64 >> q): bytes (d >> q) & 0x01010101 -> 0x00 / 0xFF masks -> select between the two byte patterns
+  for (int e = tid; e < TAPS * GG * 64; e += NT) {
+    const int L = e & 63, tj = e >> 6;
+    const int fj = tj / TAPS, ft = tj - fj * TAPS;                                               // fragment order: word-major
+    const unsigned long long w = a.wbits[(long long)(ft * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
+    const unsigned d = (L >> 5) ? (unsigned)(w >> 32) : (unsigned)w;
+    v4i out[2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned mag = q < 7 ? (64u >> q) : 64u;
+      const unsigned pos = mag * kM0, neg = ((256u - mag) & 0xFFu) * kM0;
+      const unsigned ones = (d >> q) & kM0;
+      const unsigned mask = (ones << 8) - ones;                                                  // 0xFF where the bit is set
+      out[q >> 2][q & 3] = (int)(neg ^ ((pos ^ neg) & mask));
+    }
+    s_w[2 * tj][L] = out[0];
+    s_w[2 * tj + 1][L] = out[1];
+  }
+  for (int i = tid; i < TAPS * 32; i += NT) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
+  if (tid < 32) {
+    s_scale[tid] = a.wscale[o0 + tid];
+    s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < 8 * 8 * 32; i += NT) {
+    const int o = i & 31, bw = (i >> 5) & 7, bh = i >> 8;
+    int v = 0;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+      const bool outside = ((bh >> (tp / 3)) & 1) | ((bw >> (tp % 3)) & 1);
+      v -= outside ? 0 : s_ws[tp][o];
+    }
+    s_fc[bh][bw][o] = (short)v;
+  }
+  __syncthreads();
+  v4i wreg[WREG ? NF : 1];
+  if (WREG) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) wreg[f] = s_w[f][lane];
+  }
+
+  if (!have_tile) return;
+
+  // ---- tiles ------------------------------------------------------------------------------------------------------
   constexpr int kRing = 3;                       // weight fragments of kRing consecutive (word, tap) steps; 9 GG % kRing == 0
   v4i wring[kRing][2];
   if (!WREG) {
