@@ -28,14 +28,16 @@ def _layer(xq, alpha):
 
 
 def imagenet_arch(x_quant='ls-2', alpha=3):
-    """arch_config of examples/imagenet/imagenet_ls1_weight_ls2_activation_kd.yaml (model section)."""
+    """arch_config of examples/imagenet/imagenet_ls1_weight_<x_quant>_activation_kd.yaml (model section): the ls-2
+    file uses ReLU blocks, the fp / ls-T / gf-2 / ls-1 files PReLU ones."""
     return {
         'moving_average_mode': 'off', 'moving_average_momentum': 0.99, 'block': 'xnor',
         'layer0': {'n_in_channels': 64, 'kernel_size': 7, 'stride': 2, 'padding': 3, 'bias': False,
                    'maxpool': {'type': 'maxpool2d', 'kernel_size': 3, 'stride': 2, 'padding': 1}},
         'layer1': _layer(x_quant, alpha), 'layer2': _layer(x_quant, alpha),
         'layer3': _layer(x_quant, alpha), 'layer4': _layer(x_quant, alpha),
-        'nonlins': ['relu', 'relu'], 'num_blocks': [2, 2, 2, 2], 'output_classes': 1000}
+        'nonlins': ['relu', 'relu'] if x_quant == 'ls-2' else ['prelu', 'prelu'], 'num_blocks': [2, 2, 2, 2],
+        'output_classes': 1000}
 
 
 def build_model(arch, device):
@@ -86,6 +88,7 @@ def cifar_arch():
     """arch_config of examples/cifar100/cifar100_ls1_kd.yaml (model section): 18-layer XNOR ResNet, 3x3 stem, no
     max-pool, ls-1 weights AND activations, clamp alpha = 2."""
     a = imagenet_arch('ls-1', 2)
+    a['nonlins'] = ['relu', 'relu']
     a['layer0'] = {'n_in_channels': 64, 'kernel_size': 3, 'stride': 1, 'padding': 1, 'bias': False,
                    'maxpool': {'type': 'identity'}}
     a['output_classes'] = 100

@@ -37,7 +37,13 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 4
+#define LSQ_ABI_VERSION 5
+
+/* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
+#define LSQ_ACT_NONE 0
+#define LSQ_ACT_RELU 1
+#define LSQ_ACT_PRELU 2            /* x > 0 ? x : slope[0] * x */
+#define LSQ_ACT_PRELU_CHANNEL 3    /* x > 0 ? x : slope[o] * x */
 
 /* quantization schemes (quant/binary/binary_conv.py:99-101) */
 enum {
@@ -133,15 +139,17 @@ int lsq_pack_weight(const float* w, const lsq_conv_geom* g, int k, const float* 
  * which equals F.conv2d(x_q, w_q, bias, ...) of binary_conv.py:165-173 for
  * x_q = sum_p xs_p b_p, w_q = sum_q ws_q s_q (exact integer inner products).
  *   kx, kw_planes  number of activation / weight planes
- *   relu, res_pre, res_post   optional fused block epilogue, y = relu?(conv + bias + res_pre) + res_post
+ *   act, act_slope, res_pre, res_post   optional fused block epilogue, y = act(conv + bias + res_pre) + res_post
  *                  (the non-linearity and shortcut additions of quant/models/resnet.py:95-100, :182-190);
+ *                  act: LSQ_ACT_NONE / LSQ_ACT_RELU / LSQ_ACT_PRELU (one slope, act_slope[0], nn.PReLU()) /
+ *                  LSQ_ACT_PRELU_CHANNEL (act_slope[o]); act_slope is a device pointer, NULL unless a PReLU;
  *                  residuals are [N][O][Ho][Wo] fp32 or NULL
  *   y              out, [N][O][Ho][Wo] fp32
  */
 int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
                     const uint64_t* wbits, const int32_t* wsum, int kw_planes,
                     const float* wscales, const float* bias, const lsq_conv_geom* g,
-                    int relu, const float* res_pre, const float* res_post,
+                    int act, const float* act_slope, const float* res_pre, const float* res_post,
                     float* y, void* stream);
 
 /*
@@ -152,7 +160,7 @@ int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
 int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, const float* pre_shift,
                      const uint64_t* wbits, int kw_planes,
                      const float* wscales, const float* bias, const lsq_conv_geom* g,
-                     int relu, const float* res_pre, const float* res_post,
+                     int act, const float* act_slope, const float* res_pre, const float* res_post,
                      float* y, void* stream);
 
 /*

@@ -37,7 +37,8 @@ struct SwArgs {
   int Gg, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
   int accumulate;
   int final_pass;
-  int relu;                            // epilogue: y = relu(conv + bias + res_pre) + res_post
+  int relu;                            // epilogue: y = act(conv + bias + res_pre) + res_post; LSQ_ACT_*
+  const float* slope;                  // PReLU slope(s): [1] or [O]
   const float* res_pre;                // [N][O][Ho][Wo] or null
   const float* res_post;
 };
@@ -108,7 +109,7 @@ __device__ __forceinline__ void store_tiles(const SwArgs& a, const f32x16 (&acc)
       // batch of 8 out-channel rows x TN pixel tiles: every load of the batch (previous partial sum,
       // residuals, scale, bias) is issued before the first use -- a load consumed right after it is issued
       // costs one memory latency per output
-      float ws[8], bs[8], prev[8][TN], r1[8][TN], r2[8][TN];
+      float ws[8], bs[8], sl[8], prev[8][TN], r1[8][TN], r2[8][TN];
       Off yo[8][TN];
       bool ok[8][TN];
 #pragma unroll
@@ -120,6 +121,7 @@ __device__ __forceinline__ void store_tiles(const SwArgs& a, const f32x16 (&acc)
         const int o = o0 + (rok ? ol : 0);
         ws[qq] = a.wscale[o];
         bs[qq] = (!a.accumulate && a.bias) ? a.bias[o] : 0.f;
+        sl[qq] = (a.final_pass && a.relu >= LSQ_ACT_PRELU) ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o] : 0.f;
         const Off rowoff = (Off)4 * (Off)olu * (Off)HoWo;                 // scalar
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -137,7 +139,8 @@ __device__ __forceinline__ void store_tiles(const SwArgs& a, const f32x16 (&acc)
           float out = (a.accumulate ? prev[qq][j] : bs[qq]) + acc[i][j][qh * 8 + qq] * ws[qq];
           if (a.final_pass) {
             out += r1[qq][j];
-            if (a.relu) out = fmaxf(out, 0.f);
+            if (a.relu == LSQ_ACT_RELU) out = fmaxf(out, 0.f);
+            else if (a.relu >= LSQ_ACT_PRELU) out = out > 0.f ? out : sl[qq] * out;
             out += r2[qq][j];
           }
           if (ok[qq][j]) *reinterpret_cast<float*>(yb + yo[qq][j]) = out;
@@ -599,7 +602,8 @@ using namespace lsq;
 
 extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, const float* pre_shift,
                                 const uint64_t* wbits, int kw_planes, const float* wscales, const float* bias,
-                                const lsq_conv_geom* g, int relu, const float* res_pre, const float* res_post,
+                                const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
+                                const float* res_post,
                                 float* y, void* stream) {
   if (!x || !wbits || !wscales || !y) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
@@ -610,7 +614,8 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
   if ((pre_scale == nullptr) != (pre_shift == nullptr)) return LSQ_E_NULL;
   a.x = x; a.bias = bias; a.y = y; a.alpha = clamp_alpha;
   a.pre_scale = pre_scale; a.pre_shift = pre_shift;
-  a.relu = relu; a.res_pre = res_pre; a.res_post = res_post;
+  if (relu < LSQ_ACT_NONE || relu > LSQ_ACT_PRELU_CHANNEL || (relu >= LSQ_ACT_PRELU && !act_slope)) return LSQ_E_SCHEME;
+  a.relu = relu; a.slope = act_slope; a.res_pre = res_pre; a.res_post = res_post;
   a.N = g->N; a.C = g->C; a.H = g->H; a.W = g->W; a.O = g->O; a.KH = g->KH; a.KW = g->KW;
   a.sh = g->stride_h; a.sw = g->stride_w; a.ph = g->pad_h; a.pw = g->pad_w; a.dh = g->dil_h; a.dw = g->dil_w;
   a.cg = g->C / g->groups;

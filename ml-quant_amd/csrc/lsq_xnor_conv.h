@@ -20,7 +20,8 @@ struct ConvArgs {
   int Gg, Gt, Hp, Wp, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
   int accumulate;
   int final_pass;                      // last launch of a multi-plane sequence: apply the epilogue
-  int relu;                            // epilogue: y = relu(conv + bias + res_pre) + res_post
+  int relu;                            // epilogue: y = act(conv + bias + res_pre) + res_post; LSQ_ACT_*
+  const float* slope;                  // PReLU slope(s): [1] (LSQ_ACT_PRELU) or [O] (LSQ_ACT_PRELU_CHANNEL)
   const float* res_pre;                // [N][O][Ho][Wo] or null
   const float* res_post;
   int dbg_no_corr;                     // tuning builds only

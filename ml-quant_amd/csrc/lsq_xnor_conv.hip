@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void xnor_conv_kernel(ConvArgs a) {
       float out = fmaf(v, a.wscale[o0 + o], base);
       if (a.final_pass) {        // fused block epilogue (non-linearity and shortcut adds of resnet.py:182-190)
         if (want_pre) out += rv[o];
-        if (a.relu) out = fmaxf(out, 0.f);
+        if (a.relu == LSQ_ACT_RELU) out = fmaxf(out, 0.f);
+        else if (a.relu >= LSQ_ACT_PRELU) out = out > 0.f ? out : a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o0 + o] * out;
         if (want_post) out += want_pre ? a.res_post[ybase + (long long)o * HoWo] : rv[o];
       }
       yp[(long long)o * HoWo] = out;
@@ -249,7 +250,8 @@ extern "C" void lsq_debug_xnor_impl(int popcount_only) { g_force_popcount = popc
 
 extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
                                const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
-                               const lsq_conv_geom* g, int relu, const float* res_pre, const float* res_post,
+                               const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
+                               const float* res_post,
                                float* y, void* stream) {
   if (!xplanes || !xscales || !wbits || !wsum || !wscales || !y) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
@@ -274,7 +276,9 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
     for (int kw = 0; kw < g->KW; ++kw) a.tap_xoff[kh * g->KW + kw] = kh * g->dil_h * a.Wp + kw * g->dil_w;
   a.bias = bias;
   a.y = y;
+  if (relu < LSQ_ACT_NONE || relu > LSQ_ACT_PRELU_CHANNEL || (relu >= LSQ_ACT_PRELU && !act_slope)) return LSQ_E_SCHEME;
   a.relu = relu;
+  a.slope = act_slope;
   a.res_pre = res_pre;
   a.res_post = res_post;
   const long long wplane_words = lsq_weight_plane_words(g);

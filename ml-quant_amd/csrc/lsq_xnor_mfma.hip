@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   // with that border pattern adds to 2 * (matrix-core sum).  3 x 3 taps: 8 x 8 patterns, one table look-up per
   // output instead of loops over kernel rows and columns.
   __shared__ __attribute__((aligned(16))) short s_fc[8][8][32];    // |.| <= taps * channels = 4608
-  __shared__ __attribute__((aligned(16))) float s_scale[32], s_bias[32];
+  __shared__ __attribute__((aligned(16))) float s_scale[32], s_bias[32], s_slope[32];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int o0 = blockIdx.y * 32;
@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   const int d_r = (int)(dstep - (unsigned)d_n * (unsigned)HoWo);
   const int d_ho = d_r / a.Wo, d_wo = d_r - d_ho * a.Wo;
   const bool acc_in = a.accumulate != 0, fin = a.final_pass != 0;
-  const bool want_pre = fin && a.res_pre, want_post = fin && a.res_post, relu = fin && a.relu;
+  const bool want_pre = fin && a.res_pre, want_post = fin && a.res_post;
+  const bool relu = fin && a.relu == LSQ_ACT_RELU, prelu = fin && a.relu >= LSQ_ACT_PRELU;
   const int ob = 4 * hh;                         // the lane's out-channel of register i: ob + (i & 3) + 8 (i >> 2)
 
   struct Pix {
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   if (tid < 32) {
     s_scale[tid] = a.wscale[o0 + tid];
     s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
+    s_slope[tid] = a.relu >= LSQ_ACT_PRELU ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o0 + tid] : 0.f;   // (0: ReLU)
   }
   __syncthreads();
   for (int i = tid; i < 8 * 8 * 32; i += NT) {
@@ -297,6 +299,10 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       if (relu) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) outv[i] = fmaxf(outv[i], 0.f);
+      }
+      if (prelu) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) outv[i] = outv[i] > 0.f ? outv[i] : s_slope[ob + (i & 3) + 8 * (i >> 2)] * outv[i];
       }
       if (want_post && !want_pre) {
 #pragma unroll

@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -62,9 +62,9 @@ def _declare(lib):
     lib.lsq_pack_weight.restype = i32
     lib.lsq_pack_weight.argtypes = [vp, gp, i32, vp, vp, vp, vp]
     lib.lsq_xnor_conv2d.restype = i32
-    lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
+    lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp, vp]
     lib.lsq_signw_conv2d.restype = i32
-    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp]
+    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp, vp]
     lib.lsq_pool_bias_relu_nhwc.restype = i32
     lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     lib.lsq_pointwise_conv.restype = i32
@@ -245,29 +245,47 @@ def out_hw(geom: ConvGeom):
     return ho, wo
 
 
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_PRELU_CHANNEL = 0, 1, 2, 3
+
+
+def _act(relu: bool, prelu: Optional[torch.Tensor], out_channels: int):
+    """(LSQ_ACT_* code, slope pointer) of the fused epilogue: ``prelu`` is an nn.PReLU weight (1 or O slopes)."""
+    if prelu is None:
+        return (ACT_RELU if relu else ACT_NONE), None
+    if relu:
+        raise LsqHipError('relu and prelu are exclusive')
+    w = _f32c(prelu.detach())
+    if w.numel() not in (1, out_channels):
+        raise LsqHipError(f'PReLU with {w.numel()} slopes on {out_channels} channels')
+    return (ACT_PRELU if w.numel() == 1 else ACT_PRELU_CHANNEL), w
+
+
 def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: torch.Tensor, wsum: torch.Tensor,
                 wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor,
                 relu: bool = False, res_pre: Optional[torch.Tensor] = None,
-                res_post: Optional[torch.Tensor] = None) -> None:
-    """y = relu?(conv + bias + res_pre) + res_post (the fused block epilogue is optional)."""
+                res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None) -> None:
+    """y = act(conv + bias + res_pre) + res_post, act = ReLU (``relu``), PReLU (``prelu`` = its weight) or identity
+    (the fused block epilogue is optional)."""
+    act, slope = _act(relu, prelu, geom.O)
     m = geom.C * geom.H * geom.W
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
     with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs):   # planes read + fp32 output written
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
-                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu),
+                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
 
 
 def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,
                  bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor, pre: Optional[tuple] = None,
                  relu: bool = False, res_pre: Optional[torch.Tensor] = None,
-                 res_post: Optional[torch.Tensor] = None) -> None:
+                 res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None) -> None:
     x = _f32c(x)
+    act, slope = _act(relu, prelu, geom.O)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
     with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel(), flops):     # fp32 input read + fp32 output written
         check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), None if pre is None else pre[0].data_ptr(),
                                      None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wscales.shape[0],
-                                     wscales.data_ptr(), ptr(bias), ctypes.byref(geom), int(relu), ptr(res_pre),
+                                     wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope), ptr(res_pre),
                                      ptr(res_post), y.data_ptr(), stream_ptr(x.device)), 'lsq_signw_conv2d')
 
 

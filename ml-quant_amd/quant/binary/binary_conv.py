@@ -173,18 +173,22 @@ class QuantConv2d(nn.Conv2d):
         return hit[1], hit[2], hit[3]
 
     def fused_forward(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
-                      res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``relu?(self(pre_bn(x)) + res_pre) + res_post`` -- one residual-block half (quant/models/resnet.py:
-        95-100, 182-190).  On the HIP path the eval-mode batch norm is folded into the quantizer's read
-        and the non-linearity / shortcut additions into the convolution's epilogue, so none of them is
-        a separate pass over HBM; elsewhere it is the plain composition of the modules."""
+                      res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
+                      prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``act(self(pre_bn(x)) + res_pre) + res_post`` -- one residual-block half (quant/models/resnet.py:
+        95-100, 182-190); ``act`` = ReLU (``relu=True``), PReLU (``prelu`` = the nn.PReLU weight) or identity.
+        On the HIP path the eval-mode batch norm is folded into the quantizer's read and the non-linearity /
+        shortcut additions into the convolution's epilogue, so none of them is a separate pass over HBM;
+        elsewhere it is the plain composition of the modules."""
         if self._wants_hip(x) and (pre_bn is None or (not pre_bn.training and pre_bn.track_running_stats)):
-            return self._forward_hip(x, pre_bn, relu, res_pre, res_post)
+            return self._forward_hip(x, pre_bn, relu, res_pre, res_post, prelu)
         y = self(x if pre_bn is None else pre_bn(x))
         if res_pre is not None:
             y = y + res_pre
         if relu:
             y = torch.relu(y)
+        if prelu is not None:
+            y = F.prelu(y, prelu)
         return y if res_post is None else y + res_post
 
     def _folded_bn(self, bn: nn.BatchNorm2d):
@@ -202,7 +206,8 @@ class QuantConv2d(nn.Conv2d):
         return hit[1], hit[2]
 
     def _forward_hip(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
-                     res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
+                     prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
         from quant import _hip
         x = x.detach()
         pre = None if pre_bn is None else self._folded_bn(pre_bn)
@@ -217,7 +222,7 @@ class QuantConv2d(nn.Conv2d):
         y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
         bias = None if self.bias is None else self.bias.detach()
         if self.x_quant == 'fp':
-            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y, pre, relu, res_pre, res_post)
+            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y, pre, relu, res_pre, res_post, prelu)
             return y
         xq = self.x_approximate
         k = xq.n_planes
@@ -240,6 +245,6 @@ class QuantConv2d(nn.Conv2d):
         if forced is not None:
             forced = forced.to(device=x.device, dtype=torch.float32).contiguous()
         _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced, pre)
-        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post)
+        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)
         self.last_act_scales = scales
         return y

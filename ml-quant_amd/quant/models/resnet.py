@@ -207,11 +207,12 @@ class XnorBasicBlock(nn.Module):
             # eval on the GPU: bn -> quantizer and conv -> relu -> (+shortcut) each collapse into one
             # kernel pair (QuantConv2d.fused_forward); same arithmetic as the modular path below
             sc = self.shortcut(x)
+            a1, a2 = _act_args(self.nonlin1), _act_args(self.nonlin2)
             if self.double_shortcut:
-                first = self.conv1.fused_forward(x, self.bn1, relu=True, res_post=sc)
-                return self.conv2.fused_forward(first, self.bn2, relu=True, res_post=first)
-            first = self.conv1.fused_forward(x, self.bn1, relu=True)
-            return self.conv2.fused_forward(first, self.bn2, relu=True, res_pre=sc)
+                first = self.conv1.fused_forward(x, self.bn1, res_post=sc, **a1)
+                return self.conv2.fused_forward(first, self.bn2, res_post=first, **a2)
+            first = self.conv1.fused_forward(x, self.bn1, **a1)
+            return self.conv2.fused_forward(first, self.bn2, res_pre=sc, **a2)
         first = self.nonlin1(self.conv1(self.bn1(x)))
         if self.double_shortcut:
             first = first + self.shortcut(x)
@@ -222,8 +223,19 @@ class XnorBasicBlock(nn.Module):
 
 def _fusable(block: nn.Module, x: torch.Tensor) -> bool:
     """Fused HIP path: eval mode, CUDA input, ReLU non-linearities, weights binarized (QuantConv2d decides)."""
-    return (not block.training and x.is_cuda and FUSE_BLOCKS and isinstance(block.nonlin1, nn.ReLU)
-            and isinstance(block.nonlin2, nn.ReLU) and block.conv1._wants_hip(x))
+    return (not block.training and x.is_cuda and FUSE_BLOCKS and _act_args(block.nonlin1) is not None
+            and _act_args(block.nonlin2) is not None and block.conv1._wants_hip(x))
+
+
+def _act_args(nonlin: nn.Module):
+    """fused_forward's keyword arguments for one of non_linearity_map's modules (None: not fusable)."""
+    if isinstance(nonlin, nn.ReLU):
+        return {'relu': True}
+    if isinstance(nonlin, nn.PReLU) and nonlin.weight.dtype == torch.float32:
+        return {'prelu': nonlin.weight}
+    if isinstance(nonlin, nn.Identity):
+        return {}
+    return None
 
 
 #: set to False to run residual blocks as separate BN / QuantConv2d / ReLU / add modules on the GPU too

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(hip):
     lib = hip.lib()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.lsq_abi_version() == 4
+    assert lib.lsq_abi_version() == 5
     assert lib.lsq_error_string(0) == b'ok'
     assert b'NULL' in lib.lsq_error_string(-1)
 
@@ -57,7 +57,7 @@ def test_geometry_helpers_and_argument_errors(hip):
     # null pointers / bad schemes are rejected before any launch
     assert lib.lsq_act_quant(None, ctypes.byref(g), 1, 1, 3, 2.0, None, None, None, None, None, None, 0, None) == -1
     assert lib.lsq_solve_rows(None, 1, 1, 1, 0, -1.0, None, None, None, 0, None) == -1
-    assert lib.lsq_xnor_conv2d(None, 1, None, None, None, 1, None, None, ctypes.byref(g), 0, None, None, None, None) == -1
+    assert lib.lsq_xnor_conv2d(None, 1, None, None, None, 1, None, None, ctypes.byref(g), 0, None, None, None, None, None) == -1
 
 
 def test_cuda_path_has_no_fallback(monkeypatch, hip):
