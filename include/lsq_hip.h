@@ -181,8 +181,10 @@ int lsq_pool_bias_relu_nhwc(const float* x_nhwc, int N, int C, int H, int W, int
  * Replaces Sequential(conv1, bn1, relu, maxpool) of the reference's QResNet (quant/models/resnet.py: __init__
  * layer0, forward :393-397) in front of the first QuantConv2d.  x [N,3,H,W] fp32 NCHW (W even, 8-byte aligned),
  * w [64,3,7,7], bias [64], y [N,64,Hp,Wp] with Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (same for W).
- * bf16 MFMA on operands split into `split` bf16 terms, fp32 accumulation: split = 3 (six passes, dropped terms
- * <= 2^-24 relative per product: fp32 rounding level) or 2 (three passes, ~2^-17 relative per product).
+ * 16-bit MFMA on split fp32 operands, fp32 accumulation.  split = 3: three bf16 terms (six passes, dropped terms
+ * <= 2^-24 relative per product: fp32 rounding level, any finite operand); 2: two bf16 terms (three passes, ~2^-17
+ * per product); 22: fp16 leading term + fp16 remainder scaled by 2^11 (three passes, 2^-23 per product; operands
+ * must be below 65504 in magnitude -- beyond that the leading term is inf and so is the output).
  */
 int lsq_stem_conv_pool(const float* x, int N, int H, int W, const float* w, const float* bias, int split,
                        float* y, void* stream);

@@ -7,8 +7,12 @@
 // 112x112x64 convolution output (822 MB at batch 256) written to HBM and read back in between.  Here the
 // convolution output never leaves the chip.
 //
-// Arithmetic: bf16 MFMA (v_mfma_f32_32x32x16_bf16) on fp32 operands split into bf16 terms, fp32 accumulation.
-//   SPLIT = 3 (default): x = h + m + l (each the bf16 rounding of what is left; the remainders are exact in fp32),
+// Arithmetic: 16-bit MFMA on fp32 operands split into 16-bit terms, fp32 accumulation.
+//   fp16 terms (split code 22, the host default): x = h + l 2^-11 with h = fp16(x), l = fp16((x - h) 2^11): 22 bits of
+//     x in two terms, three passes hh + (hl + lh) 2^-11, 2^-23 per product -- as accurate as three bf16 terms at half
+//     the MFMA work (measured 2.0e-7 of max|y| against fp64, torch's own fp32 convolution 5.4e-7).  Operands must
+//     be below 65504 in magnitude (normalised images, folded weights): beyond that h is inf and so is the output.
+//   SPLIT = 3 (any finite operand): x = h + m + l (each the bf16 rounding of what is left; the remainders are exact in fp32),
 //     six passes hh + (hm + mh) + (hl + lh + mm); the dropped terms are <= 2^-24 relative per product, i.e. fp32
 //     rounding level -- a binarized network amplifies any perturbation in front of its first quantizer (one
 //     flipped sign is worth 3 % of a block's output), so the stem keeps fp32-class accuracy.
@@ -43,17 +47,35 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 union Frag {
   unsigned u[4];
   bf16x8 v;
+  __attribute__((ext_vector_type(8))) _Float16 h;
 };
 
-// two fp32 values -> SPLIT packed bf16 pairs t[0] (leading term) .. t[SPLIT - 1]; x - t[0] - ... is exact in fp32
-template <int SPLIT>
+// two fp32 values -> SPLIT packed 16-bit pairs t[0] (leading term) .. t[SPLIT - 1].
+// bf16 terms (HALF = false): each the bf16 rounding of what is left; x - t[0] - ... is exact in fp32.
+// fp16 terms (HALF = true, SPLIT = 2): h = fp16(x), l = fp16((x - h) * 2^11) -- the remainder is at most 2^-12 |x|, and
+// scaled up it is an ordinary fp16 number with 11 significant bits instead of a subnormal; the cross-term accumulator
+// is scaled back by 2^-11 (exact).  h + l 2^-11 carries 22 bits of x: products are good to 2^-23 with THREE MFMA
+// passes where bf16 needs six.  Domain: |x| below the largest fp16 (65504).
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+constexpr float kLoScale = 2048.f;
+
+template <int SPLIT, bool HALF>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&t)[SPLIT]) {
   f32x2 r = {x0, x1};
+  if constexpr (HALF) {
+    static_assert(SPLIT == 2, "fp16 terms: two");
+    const f16x2 h = __builtin_convertvector(r, f16x2);
+    t[0] = __builtin_bit_cast(unsigned, h);
+    r = (r - __builtin_convertvector(h, f32x2)) * kLoScale;
+    t[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+  } else {
 #pragma unroll
-  for (int i = 0; i < SPLIT; ++i) {
-    const bf16x2 b = __builtin_convertvector(r, bf16x2);
-    t[i] = __builtin_bit_cast(unsigned, b);
-    r = r - __builtin_convertvector(b, f32x2);
+    for (int i = 0; i < SPLIT; ++i) {
+      const bf16x2 b = __builtin_convertvector(r, bf16x2);
+      t[i] = __builtin_bit_cast(unsigned, b);
+      r = r - __builtin_convertvector(b, f32x2);
+    }
   }
 }
 
@@ -79,7 +101,7 @@ struct StemLds {
   float carry[kCR][2][2][16];             // last conv column of the previous chunk: [row][out-channel tile][lane half][reg]
 };
 
-template <int SPLIT>
+template <int SPLIT, bool HALF>
 __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   // two workgroups per CU: <= 256 registers (VGPR + AGPR)
   __shared__ StemLds<SPLIT> lds;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned t[SPLIT];
-        split_pair<SPLIT>(v[2 * j], v[2 * j + 1], t);
+        split_pair<SPLIT, HALF>(v[2 * j], v[2 * j + 1], t);
 #pragma unroll
         for (int i = 0; i < SPLIT; ++i) af[i][s].u[j] = t[i];
       }
@@ -153,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
         for (int it = h0; it < h0 + kHalf; ++it) {
           if (it < kIt && tid + 256 * it < kPairs) {
             unsigned sp[SPLIT];
-            split_pair<SPLIT>(t[it - h0].x, t[it - h0].y, sp);
+            split_pair<SPLIT, HALF>(t[it - h0].x, t[it - h0].y, sp);
 #pragma unroll
             for (int i = 0; i < SPLIT; ++i) lds.xs[i][tid + 256 * it] = sp[i];
           }
@@ -186,13 +208,19 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
         if (s + 1 < kSteps) load_b(s + 1, (s + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         const Frag* b = bf[s & 1];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[0].v, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[1].v, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[0].v, acc1, 0, 0, 0);
-        if constexpr (SPLIT == 3) {
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[2].v, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][s].v, b[0].v, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[1].v, acc1, 0, 0, 0);
+        if constexpr (HALF) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][s].h, b[0].h, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][s].h, b[1].h, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][s].h, b[0].h, acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[0].v, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[1].v, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[0].v, acc1, 0, 0, 0);
+          if constexpr (SPLIT == 3) {
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[2].v, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][s].v, b[0].v, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[1].v, acc1, 0, 0, 0);
+          }
         }
       }
       // lane: pixel x = 32 ck + xl_, out-channels mt * 32 + (reg & 3) + 8 (reg >> 2) + 4 g.  Horizontal 3-max with
@@ -202,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int ch = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
-        const float v = x_ok ? acc1[reg] + acc0[reg] : ninf;
+        const float v = x_ok ? (HALF ? fmaf(acc1[reg], 1.f / kLoScale, acc0[reg]) : acc1[reg] + acc0[reg]) : ninf;
         const int vi = __float_as_int(v);
         float left = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xF, 0xF, false));    // wave_shr:1
         const float right = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xF, 0xF, false));   // wave_shl:1
@@ -261,7 +289,7 @@ extern "C" int lsq_stem_conv_pool(const float* x, int N, int H, int W, const flo
                                   float* y, void* stream) {
   if (!x || !w || !bias || !y) return LSQ_E_NULL;
   if (N <= 0 || H < 8 || W < 8 || (W & 1) || ((uintptr_t)x % 8)) return LSQ_E_SHAPE;
-  if (split != 2 && split != 3) return LSQ_E_SCHEME;
+  if (split != 2 && split != 3 && split != 22) return LSQ_E_SCHEME;
   StemArgs a = {};
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   a.N = N; a.H = H; a.W = W;
@@ -271,7 +299,8 @@ extern "C" int lsq_stem_conv_pool(const float* x, int N, int H, int W, const flo
   a.Wp = (a.Wc + 2 - 3) / 2 + 1;
   const long long blocks = (long long)N * ((a.Hp + kPH - 1) / kPH);
   if (blocks > 0x7FFFFFFF) return LSQ_E_SHAPE;
-  if (split == 3) hipLaunchKernelGGL(stem_conv_pool_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(stem_conv_pool_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (split == 3) hipLaunchKernelGGL((stem_conv_pool_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (split == 2) hipLaunchKernelGGL((stem_conv_pool_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((stem_conv_pool_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

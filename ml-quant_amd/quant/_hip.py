@@ -307,8 +307,11 @@ def pool_bias_relu_nhwc(x: torch.Tensor, kernel: int, stride: int, pad: int, bia
 
 def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: int = 3) -> torch.Tensor:
     """``max_pool2d(relu(conv2d(x, w, stride=2, padding=3) + bias), 3, 2, 1)`` for a 7x7 convolution 3 -> 64
-    channels (batch norm already folded into ``w`` / ``bias``) as ONE kernel, NCHW fp32 in and out.  ``split``:
-    bf16 terms per fp32 operand (3: fp32-class accuracy, six MFMA passes; 2: ~2^-17 per product, three passes)."""
+    channels (batch norm already folded into ``w`` / ``bias``) as ONE kernel, NCHW fp32 in and out.  ``split``: how the
+    fp32 operands are fed to the 16-bit matrix cores -- 3: three bf16 terms, six MFMA passes, fp32-class accuracy, any
+    finite input; 2: two bf16 terms, three passes, ~2^-17 per product; 22: fp16 leading term + scaled fp16 remainder,
+    three passes, fp32-class accuracy (2^-23 per product), operands below 65504 in magnitude (larger ones become
+    inf / nan in the output: normalised images are far inside)."""
     x, w, bias = _f32c(x), _f32c(w), _f32c(bias)
     n, c, h, wd = x.shape
     if c != 3 or tuple(w.shape) != (64, 3, 7, 7) or wd % 2:
@@ -316,7 +319,7 @@ def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: 
     hc, wc = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
     hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
     y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device)
-    flops = 2 * (6 if split == 3 else 3) * n * 64 * hc * wc * 147      # bf16 passes issued
+    flops = 2 * (6 if split == 3 else 3) * n * 64 * hc * wc * 147      # 16-bit MFMA passes issued
     with _on(x), _Timed('lsq_stem_conv_pool', 4 * x.numel() + 4 * y.numel(), flops):
         check(lib().lsq_stem_conv_pool(x.data_ptr(), n, h, wd, w.data_ptr(), bias.data_ptr(), int(split), y.data_ptr(),
                                        stream_ptr(x.device)), 'lsq_stem_conv_pool')

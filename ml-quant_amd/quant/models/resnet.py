@@ -63,7 +63,7 @@ def _square_pool(pool: nn.Module):
 FUSED_STEM = True
 #: bf16 terms per fp32 operand in the fused stem: 3 = fp32-class accuracy (six MFMA passes, 0.70 ms at batch 256),
 #: 2 = ~2^-17 per product (three passes, 0.49 ms) -- measurably more sign flips in the first quantizers
-STEM_SPLIT = 3
+STEM_SPLIT = 22     # 22: fp16 hi + scaled fp16 lo, three MFMA passes (|x|, |w| < 65504); 3: three bf16 terms, six passes
 
 
 def _is_resnet_stem(conv: nn.Conv2d, relu: nn.Module, pool: nn.Module, x: torch.Tensor) -> bool:
