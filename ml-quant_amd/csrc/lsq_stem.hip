@@ -139,50 +139,67 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 
   const float* __restrict__ xn = a.x + (long long)n * 3 * a.H * a.W;
   const int chunks = (a.Wc + 31) / 32;
+  // ---- staging of the input patch: pairs of columns, fp32 -> 16-bit terms.  Pair e = tid + 256 it of the [3][23][36]
+  // patch: 256 = 7 * 36 + 4, so (c, row, pair) advance without divisions; W is even and the patch starts at an even
+  // column, so a pair is inside the image or outside it as a whole.
+  constexpr int kPairs = 3 * kIR * (kIC / 2), kIt = (kPairs + 255) / 256;
+  // PREFETCH (the two-term variants have the registers): all ten loads of a lane's share of the NEXT chunk are issued
+  // before this chunk's MFMAs and converted after them -- the patch's memory latency, paid three times per chunk
+  // with four loads in flight, was 118 of the kernel's 729 us.
+  constexpr bool kPrefetch = SPLIT == 2;
+  constexpr int kHalf = kPrefetch ? kIt : 4;                                      // loads in flight per lane
+  float2 pre[kPrefetch ? kIt : 1];
+  auto request = [&](int ck, int h0, float2* t) {                                 // iterations h0 .. h0 + kHalf - 1
+    const int ic0 = 64 * ck - 4;                                                  // input column of staged column 0
+    int pp = tid % (kIC / 2), rr = tid / (kIC / 2), c = 0;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      if (it >= h0 && it < h0 + kHalf) {
+        const int ir = ir0 + rr, ic = ic0 + 2 * pp;
+        const bool in = tid + 256 * it < kPairs && ir >= 0 && ir < a.H && ic >= 0 && ic < a.W;
+        t[it - h0] = make_float2(0.f, 0.f);
+        if (in) t[it - h0] = *reinterpret_cast<const float2*>(xn + ((long long)c * a.H + ir) * a.W + ic);
+      }
+      pp += 4;
+      rr += 7;
+      if (pp >= kIC / 2) {
+        pp -= kIC / 2;
+        rr += 1;
+      }
+      if (rr >= kIR) {
+        rr -= kIR;
+        c += 1;
+      }
+    }
+  };
+  auto convert = [&](int h0, const float2* t) {
+#pragma unroll
+    for (int it = h0; it < h0 + kHalf; ++it) {
+      if (it < kIt && tid + 256 * it < kPairs) {
+        unsigned sp[SPLIT];
+        split_pair<SPLIT, HALF>(t[it - h0].x, t[it - h0].y, sp);
+#pragma unroll
+        for (int i = 0; i < SPLIT; ++i) lds.xs[i][tid + 256 * it] = sp[i];
+      }
+    }
+  };
+  if constexpr (kPrefetch) request(0, 0, pre);
   for (int ck = 0; ck < chunks; ++ck) {
-    const int ic0 = 64 * ck - 4;          // input column of staged column 0
     __syncthreads();                      // the previous chunk's patch and hbuf are done with
-    // ---- stage the input patch: pairs of columns, fp32 -> bf16 hi / lo.  Pair e = tid + 256 it of the
-    // [3][23][36] patch: 256 = 7 * 36 + 4, so (c, row, pair) advance without divisions; W is even and the patch
-    // starts at an even column, so a pair is inside the image or outside it as a whole.  All loads of a lane are
-    // issued before the first conversion.
-    {
-      constexpr int kPairs = 3 * kIR * (kIC / 2), kIt = (kPairs + 255) / 256, kHalf = 4;      // loads in flight per lane
-      int pp = tid % (kIC / 2), rr = tid / (kIC / 2), c = 0;
+    if constexpr (kPrefetch) {
+      convert(0, pre);
+    } else {
 #pragma unroll
       for (int h0 = 0; h0 < kIt; h0 += kHalf) {
         float2 t[kHalf];
-#pragma unroll
-        for (int it = h0; it < h0 + kHalf; ++it) {
-          if (it < kIt) {
-            const int ir = ir0 + rr, ic = ic0 + 2 * pp;
-            const bool in = tid + 256 * it < kPairs && ir >= 0 && ir < a.H && ic >= 0 && ic < a.W;
-            t[it - h0] = make_float2(0.f, 0.f);
-            if (in) t[it - h0] = *reinterpret_cast<const float2*>(xn + ((long long)c * a.H + ir) * a.W + ic);
-            pp += 4;
-            rr += 7;
-            if (pp >= kIC / 2) {
-              pp -= kIC / 2;
-              rr += 1;
-            }
-            if (rr >= kIR) {
-              rr -= kIR;
-              c += 1;
-            }
-          }
-        }
-#pragma unroll
-        for (int it = h0; it < h0 + kHalf; ++it) {
-          if (it < kIt && tid + 256 * it < kPairs) {
-            unsigned sp[SPLIT];
-            split_pair<SPLIT, HALF>(t[it - h0].x, t[it - h0].y, sp);
-#pragma unroll
-            for (int i = 0; i < SPLIT; ++i) lds.xs[i][tid + 256 * it] = sp[i];
-          }
-        }
+        request(ck, h0, t);
+        convert(h0, t);
       }
     }
     __syncthreads();
+    if constexpr (kPrefetch) {
+      if (ck + 1 < chunks) request(ck + 1, 0, pre);
+    }
 
     // ---- this wave's conv rows of the chunk
     for (int q = q0; q < kCR; q += 2) {
@@ -226,18 +243,34 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       // lane: pixel x = 32 ck + xl_, out-channels mt * 32 + (reg & 3) + 8 (reg >> 2) + 4 g.  Horizontal 3-max with
       // stride 2: the neighbours come from wave-wide one-lane shifts (DPP, no LDS round trip); lanes 0 / 32 take
       // their left neighbour -- the last column of the previous chunk -- from the carry, lanes 31 / 63 leave theirs.
+      const bool full = 32 * ck + 32 <= a.Wc;                  // (uniform) no column of the chunk is past the row's end
       const bool x_ok = 32 * ck + xl_ < a.Wc;
+      float v[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) v[reg] = HALF ? fmaf(acc1[reg], 1.f / kLoScale, acc0[reg]) : acc1[reg] + acc0[reg];
+      if (!full) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) v[reg] = x_ok ? v[reg] : ninf;
+      }
+      float4 cv[4];                                            // lanes 0 / 32: column 31 of the previous chunk
+      if (xl_ == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cv[k] = *reinterpret_cast<const float4*>(&lds.carry[q][mt][g][4 * k]);
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int ch = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
-        const float v = x_ok ? (HALF ? fmaf(acc1[reg], 1.f / kLoScale, acc0[reg]) : acc1[reg] + acc0[reg]) : ninf;
-        const int vi = __float_as_int(v);
+        const int vi = __float_as_int(v[reg]);
         float left = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xF, 0xF, false));    // wave_shr:1
         const float right = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xF, 0xF, false));   // wave_shl:1
-        if (xl_ == 0) left = lds.carry[q][mt][g][reg];
-        const float hmax = fmaxf(fmaxf(left, v), xl_ == 31 ? ninf : right);
-        if ((xl_ & 1) == 0) lds.hbuf[q][ch][xl_ >> 1] = hmax;
-        if (xl_ == 31) lds.carry[q][mt][g][reg] = v;        // (lanes 0 / 32 read theirs above)
+        if (xl_ == 0) left = reinterpret_cast<const float*>(&cv[reg >> 2])[reg & 3];
+        // (a centre is an even column: lane 31 / 63, whose right neighbour belongs to the next chunk, stores nothing)
+        if ((xl_ & 1) == 0) lds.hbuf[q][ch][xl_ >> 1] = fmaxf(fmaxf(left, v[reg]), right);
+      }
+      if (xl_ == 31) {                                         // (lanes 0 / 32 have read theirs above)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          *reinterpret_cast<float4*>(&lds.carry[q][mt][g][4 * k]) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
       }
     }
     __syncthreads();
