@@ -62,7 +62,7 @@ def pmc_traffic_per_launch(entry):
     the last profiled build's figure; None when the profiles are absent."""
     import csv
     import glob
-    prefix = {'lsq_act_quant': 'aq_', 'lsq_xnor_conv2d': 'xnor_conv_kernel', 'lsq_signw_conv2d': 'signw_conv_'}.get(entry)
+    prefix = {'lsq_act_quant': 'aq_', 'lsq_xnor_conv2d': 'xnor_', 'lsq_signw_conv2d': 'signw_conv_'}.get(entry)
     tables = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm_traffic.json')))
     steps = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_per_step_summary%s.csv' % ('_fpact' if entry == 'lsq_signw_conv2d' else ''))))
     if not prefix or not tables or not steps:
@@ -252,7 +252,10 @@ def main():
         _hip.enable_timing(True)
         step()
         torch.cuda.synchronize()
-        table = _hip.drain_timing()
+        by_shape = _hip.drain_timing(by_tag=True)
+        table = {}
+        for (name, _tag), v in by_shape.items():
+            table[name] = tuple(a + b for a, b in zip(table.get(name, (0, 0.0, 0, 0)), v))
         candidates = {k: v for k, v in table.items() if k in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d')}
         dominant = max(candidates, key=lambda k: candidates[k][1])
         _hip.enable_timing(True, only=[dominant])
@@ -347,7 +350,17 @@ def main():
                 if p:
                     kern[k]['traffic'] = p['bytes_per_launch']
                     kern[k]['algorithmic_bytes_per_launch'] = v[2] / max(v[0], 1)
+            # per layer shape: which launches are output-bound (HBM) and which matrix-core-bound
+            shapes = {}
+            for (name, tag), (cnt, ms, nb, ops) in sorted(by_shape.items(), key=lambda kv: str(kv[0])):
+                if tag is None or name not in ('lsq_act_quant', 'lsq_xnor_conv2d'):
+                    continue
+                row = {'launches': cnt, 'avg_launch_us': 1e3 * ms / cnt, 'algorithmic_GBps': nb / (ms * 1e-3) / 1e9}
+                if ops:
+                    row['T_binary_MAC_per_s'] = ops / (ms * 1e-3) / 1e12
+                shapes.setdefault(name, {})[tag] = row
             out['roofline']['kernels'] = kern
+            out['roofline']['by_layer_shape'] = shapes
             out['roofline']['kernels_measured'] = 'one fully instrumented step after the warm-up'
         if allgather is not None:
             out['allgather'] = allgather

@@ -148,20 +148,24 @@ def pause_timing(paused: bool = True) -> None:
     _timing_paused = bool(paused)
 
 
-def drain_timing():
+def drain_timing(by_tag: bool = False):
     """{kernel: (launches, total_ms, total_algorithmic_bytes, total_ops)}; call after torch.cuda.synchronize().
-    ops = binary MACs (xnor conv) or bf16 FLOPs (sign-weight conv), 0 for the quantizer."""
+    ops = binary MACs (xnor conv) or bf16 FLOPs (sign-weight conv), 0 for the quantizer.  ``by_tag``: keys are
+    (kernel, tag) with the tag the call site attached (the layer's input channels and height)."""
     out = {}
     for name, recs in (_timing or {}).items():
-        out[name] = (len(recs), sum(s.elapsed_time(e) for s, e, _ in recs), sum(b[0] for _, _, b in recs),
-                     sum(b[1] for _, _, b in recs))
+        groups = {}
+        for s, e, b in recs:
+            groups.setdefault((name, b[2]) if by_tag else name, []).append((s.elapsed_time(e), b[0], b[1]))
+        for key, rows in groups.items():
+            out[key] = (len(rows), sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows))
         recs.clear()
     return out
 
 
 class _Timed:
-    def __init__(self, name, nbytes, ops=0):
-        self.name, self.nbytes = name, (nbytes, ops)
+    def __init__(self, name, nbytes, ops=0, tag=None):
+        self.name, self.nbytes = name, (nbytes, ops, tag)
 
     def __enter__(self):
         self.on = _timing is not None and not _timing_paused and (_timing_only is None or self.name in _timing_only)
@@ -201,7 +205,7 @@ def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, a
     x = _f32c(x)
     ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) and forced is None else None
     m = geom.C * geom.H * geom.W
-    with _on(x), _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8)):     # x read once + k bit planes written
+    with _on(x), _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8), 0, f'C{geom.C}_H{geom.H}'):     # x read once + k bit planes written
         check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha),
                                   None if pre is None else pre[0].data_ptr(), None if pre is None else pre[1].data_ptr(),
                                   ptr(forced), planes.data_ptr(), scales.data_ptr(), ptr(ws),
@@ -269,7 +273,7 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
     act, slope = _act(relu, prelu, geom.O)
     m = geom.C * geom.H * geom.W
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
-    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs):   # planes read + fp32 output written
+    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}'):   # planes read + fp32 output written
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
