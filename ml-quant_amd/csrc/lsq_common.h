@@ -23,24 +23,39 @@ __device__ __forceinline__ unsigned abs_key(float x) {
 
 __device__ __forceinline__ float key_value(unsigned key) { return __uint_as_float(key); }
 
-// ---- wave-level scans / reductions on 64 lanes (DPP/ds_bpermute via __shfl) ----------------
+// ---- wave-level scans / reductions on 64 lanes -------------------------------------------------
+// Inclusive scans on DPP moves (row shifts inside the rows of 16 lanes, then the two row broadcasts): a dozen VALU
+// instructions per scan where the ds_bpermute form of __shfl_up pays six dependent LDS round trips.  A lane without
+// a source keeps `old` = 0, so the adds need no lane tests.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_or_zero(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    unsigned o = __shfl_up(v, d);
-    if (lane >= d) v += o;
-  }
+  v += dpp_or_zero<0x111, 0xF>(v);     // row_shr:1
+  v += dpp_or_zero<0x112, 0xF>(v);     // row_shr:2
+  v += dpp_or_zero<0x114, 0xF>(v);     // row_shr:4
+  v += dpp_or_zero<0x118, 0xF>(v);     // row_shr:8
+  v += dpp_or_zero<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+  v += dpp_or_zero<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3
   return v;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = dpp_or_zero<CTRL, ROW_MASK>((unsigned)u), hi = dpp_or_zero<CTRL, ROW_MASK>((unsigned)(u >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double wave_incl_scan(double v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    double o = __shfl_up(v, d);
-    if (lane >= d) v += o;
-  }
+  v += dpp_or_zero<0x111, 0xF>(v);
+  v += dpp_or_zero<0x112, 0xF>(v);
+  v += dpp_or_zero<0x114, 0xF>(v);
+  v += dpp_or_zero<0x118, 0xF>(v);
+  v += dpp_or_zero<0x142, 0xA>(v);
+  v += dpp_or_zero<0x143, 0xC>(v);
   return v;
 }
 
