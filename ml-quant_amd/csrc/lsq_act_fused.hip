@@ -50,6 +50,7 @@ constexpr int kTaskCap = 256;                  // brute-force tasks over all rou
 constexpr int kCellCap = kNodeCap + kTaskCap;  // successor cells
 constexpr int kArena = 4096;                   // captured keys of the brute-force tasks
 constexpr int kSeg3 = 8;
+constexpr int kBlkSlots = 8;                   // flagged level-1 bins the block path histograms per read of the row
 constexpr unsigned kTaskBit = 0x8000u;
 constexpr int kBnCap = 1024;                   // channels whose folded batch norm is staged in LDS
 
@@ -83,7 +84,7 @@ static constexpr int L3_BINS = 1 << L2_SHIFT;
 static constexpr int kKeysPerLane = L3_BINS / kWave;
 static_assert((L2_BINS << L2_SHIFT) == (1 << L1_SHIFT), "block path covers the 18 low key bits");
 struct BlockHists {
-  unsigned long long hist2[L2_BINS];
+  unsigned long long hist2[kBlkSlots][L2_BINS];
   unsigned hist3[kSeg3][L3_BINS];
 };
 
@@ -97,6 +98,7 @@ struct FixedLds {
   unsigned short slow[kFastSlots];
   Seg3 seg[kSeg3];
   unsigned succ3[kSeg3];
+  unsigned blk_bin[kBlkSlots], blk_next[kBlkSlots], blk_succs[kBlkSlots];   // block path: the slots of one read of the row
   unsigned wa[kWaves], wb[kWaves], wc[kWaves];
   double ws[kWaves];
   Best wbest[kWaves];
@@ -115,9 +117,13 @@ struct FusedLds : FixedLds {
     struct {                                       // pass 1 and the level-1 scan(s); blk: block path
       unsigned long long hist1[L1_BINS];
       unsigned short nzlist[L1_BINS];
-      unsigned nz_r0[kNzCap];
-      double nz_p0[kNzCap];
-      BlockHists blk;
+      union {
+        struct {
+          unsigned nz_r0[kNzCap];
+          double nz_p0[kNzCap];
+        };
+        BlockHists blk;                            // (the level-1 scan's prefix tables are dead between scans)
+      };
     } a;
     struct {                                       // on-chip refinement
       unsigned short role[L1_BINS + 2];            // level-1 bin -> low byte: node + 1; high byte: successor cell + 1 of
@@ -305,76 +311,44 @@ static __device__ __forceinline__ void for_each_row_key(const FusedArgs& a, cons
   }
 }
 
-// One flagged level-1 bin resolved with block-wide histograms of key bits [17:8] and [7:0] read from the
-// row in memory.  Fully general (any count, any ties); ~15 workgroup barriers per bin.
-static __device__ __forceinline__ Best resolve_slot_block(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned si,
-                                                   bool ternary, Best best) {
+// Flagged level-1 bins resolved with block-wide histograms of key bits [17:L2_SHIFT] and the remaining low bits,
+// read from the row in memory.  Fully general (any count, any ties).  Up to kBlkSlots bins share ONE read of the
+// row for their level-2 histograms, and their flagged level-2 bins share the reads for the level-3 histograms,
+// kSeg3 at a time -- rows with many oversized bins (the zeros of a ReLU spread over a few dozen per-channel constants
+// by the next batch norm) took two reads of the row PER BIN before.
+template <class SlotOf>
+static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned nsl,
+                                                    SlotOf slot_of, bool ternary, Best best) {
   const FusedArgs& a = lds->args;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double total = lds->total;
-  const Slot1 s1 = lds->slot[si];
-  const unsigned s1_bin = s1.bin;
-  const unsigned s1_next = s1.next_bin == 0xFFFFu ? kNoKey : (unsigned)s1.next_bin;
   __syncthreads();
-  for (int i = tid; i < L2_BINS; i += kThreads) lds->a.blk.hist2[i] = 0ull;
-  if (tid == 0) lds->blk_succ = kNoKey;
+  for (unsigned i = tid; i < nsl * (unsigned)L2_BINS; i += kThreads) (&lds->a.blk.hist2[0][0])[i] = 0ull;
+  if ((unsigned)tid < nsl) {
+    const Slot1 sl = lds->slot[slot_of((unsigned)tid)];
+    lds->blk_bin[tid] = sl.bin;
+    lds->blk_next[tid] = sl.next_bin == 0xFFFFu ? kNoKey : (unsigned)sl.next_bin;
+    lds->blk_succs[tid] = kNoKey;
+  }
   __syncthreads();
   for_each_row_key(a, xrow, n, [&](unsigned key) {
     const unsigned b = key >> L1_SHIFT;
-    if (b == s1_bin)
-      atomicAdd(&lds->a.blk.hist2[(key >> L2_SHIFT) & (L2_BINS - 1)],
-                kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
-    else if (b == s1_next && key < lds->blk_succ)
-      atomicMin(&lds->blk_succ, key);
+    for (unsigned j = 0; j < nsl; ++j) {
+      if (b == lds->blk_bin[j])
+        atomicAdd(&lds->a.blk.hist2[j][(key >> L2_SHIFT) & (L2_BINS - 1)], kOne | (unsigned long long)(key & ((1u << L2_SHIFT) - 1u)));
+      if (b == lds->blk_next[j] && key < lds->blk_succs[j]) atomicMin(&lds->blk_succs[j], key);
+    }
   });
   __syncthreads();
-  const unsigned succ_b = lds->blk_succ;
-  const unsigned long long h2 = lds->a.blk.hist2[tid];
-  const unsigned c2 = (unsigned)(h2 >> 42);
-  const unsigned hi_key2 = (s1_bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
-  const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
-  unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
-  double es2 = s2, ts2;
-  block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
-  if (c2) lds->nzlist2[enz2] = (unsigned short)tid;
-  __syncthreads();
-  const unsigned r02 = s1.r0 + ec2;
-  const double p02 = s1.p0 + es2;
-  unsigned next_sub = kNoKey;
-  bool f2 = false;
-  if (c2) {
-    const double vlo = (double)key_value(hi_key2);
-    const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
-    double next_hi = vhi;
-    if (enz2 + 1 < tnz2) {
-      next_sub = lds->nzlist2[enz2 + 1];
-      next_hi = (double)key_value((s1_bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
-    } else if (succ_b != kNoKey) {
-      next_hi = (double)key_value(succ_b);
-    }
-    f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, total, ternary);
-  }
-  unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
-  double dz2 = 0.0, tdz2;
-  block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
-  for (unsigned b3 = 0; b3 < tf2; b3 += kSeg3) {
-    const unsigned nseg = min((unsigned)kSeg3, tf2 - b3);
+
+  // level 3 for the `pend` queued segments: one read of the row, one wave per segment
+  auto flush = [&](unsigned pend) {
     __syncthreads();
-    if (f2 && ef2 >= b3 && ef2 < b3 + nseg) {
-      Seg3 g;
-      g.pref = (s1_bin << (L1_SHIFT - L2_SHIFT)) | (unsigned)tid;
-      g.next_pref = next_sub != kNoKey ? ((s1_bin << (L1_SHIFT - L2_SHIFT)) | next_sub) : kNoKey;
-      g.cnt = c2;
-      g.r0 = r02;
-      g.p0 = p02;
-      lds->seg[ef2 - b3] = g;
-      lds->succ3[ef2 - b3] = next_sub != kNoKey ? kNoKey : succ_b;
-    }
     for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->a.blk.hist3[0][0])[i] = 0u;
     __syncthreads();
     for_each_row_key(a, xrow, n, [&](unsigned key) {
       const unsigned p = key >> L2_SHIFT;
-      for (unsigned j = 0; j < nseg; ++j) {
+      for (unsigned j = 0; j < pend; ++j) {
         if (p == lds->seg[j].pref)
           atomicAdd(&lds->a.blk.hist3[j][key & (L3_BINS - 1)], 1u);
         else if (p == lds->seg[j].next_pref && key < lds->succ3[j])
@@ -382,7 +356,7 @@ static __device__ __forceinline__ Best resolve_slot_block(FusedLds* lds, const f
       }
     });
     __syncthreads();
-    if ((unsigned)wid < nseg) {
+    if ((unsigned)wid < pend) {
       const Seg3 g = lds->seg[wid];
       const unsigned succ_s = lds->succ3[wid];
       unsigned kc[kKeysPerLane];
@@ -439,7 +413,65 @@ static __device__ __forceinline__ Best resolve_slot_block(FusedLds* lds, const f
         }
       }
     }
+    __syncthreads();                               // the segment records may be overwritten
+  };
+
+  unsigned pend = 0;                               // segments queued for the next level-3 read (uniform)
+  for (unsigned j = 0; j < nsl; ++j) {
+    const Slot1 s1 = lds->slot[slot_of(j)];
+    const unsigned s1_bin = s1.bin;
+    const unsigned succ_b = lds->blk_succs[j];
+    const unsigned long long h2 = lds->a.blk.hist2[j][tid];
+    const unsigned c2 = (unsigned)(h2 >> 42);
+    const unsigned hi_key2 = (s1_bin << L1_SHIFT) | ((unsigned)tid << L2_SHIFT);
+    const double s2 = c2 ? bin_sum_exact(hi_key2, c2, h2 & kLowMask) : 0.0;
+    unsigned enz2 = c2 ? 1u : 0u, ec2 = c2, tnz2, tc2;
+    double es2 = s2, ts2;
+    block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
+    if (c2) lds->nzlist2[enz2] = (unsigned short)tid;
+    __syncthreads();
+    const unsigned r02 = s1.r0 + ec2;
+    const double p02 = s1.p0 + es2;
+    unsigned next_sub = kNoKey;
+    bool f2 = false;
+    if (c2) {
+      const double vlo = (double)key_value(hi_key2);
+      const double vhi = (double)key_value(hi_key2 | ((1u << L2_SHIFT) - 1u));
+      double next_hi = vhi;
+      if (enz2 + 1 < tnz2) {
+        next_sub = lds->nzlist2[enz2 + 1];
+        next_hi = (double)key_value((s1_bin << L1_SHIFT) | (next_sub << L2_SHIFT) | ((1u << L2_SHIFT) - 1u));
+      } else if (succ_b != kNoKey) {
+        next_hi = (double)key_value(succ_b);
+      }
+      f2 = may_hold_candidate(r02, c2, p02, s2, vlo, vhi, next_hi, n, total, ternary);
+    }
+    unsigned ef2 = f2 ? 1u : 0u, d2 = 0, tf2, td2;
+    double dz2 = 0.0, tdz2;
+    block_excl_scan(ef2, d2, dz2, tf2, td2, tdz2, lds);
+    unsigned taken = 0;                            // flagged level-2 bins of this slot already queued
+    while (taken < tf2) {
+      const unsigned take = min((unsigned)kSeg3 - pend, tf2 - taken);
+      if (f2 && ef2 >= taken && ef2 < taken + take) {
+        Seg3 g;
+        g.pref = (s1_bin << (L1_SHIFT - L2_SHIFT)) | (unsigned)tid;
+        g.next_pref = next_sub != kNoKey ? ((s1_bin << (L1_SHIFT - L2_SHIFT)) | next_sub) : kNoKey;
+        g.cnt = c2;
+        g.r0 = r02;
+        g.p0 = p02;
+        lds->seg[pend + ef2 - taken] = g;
+        lds->succ3[pend + ef2 - taken] = next_sub != kNoKey ? kNoKey : succ_b;
+      }
+      pend += take;
+      taken += take;
+      if (pend == (unsigned)kSeg3) {
+        flush(pend);
+        pend = 0;
+      }
+    }
+    __syncthreads();                               // nzlist2 and the scan scratch are reused by the next slot
   }
+  if (pend) flush(pend);
   return best;
 }
 
@@ -909,8 +941,9 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
     nslot = min((unsigned)kSlotCap, tflag);
   }
   while (nslot) {
-    for (unsigned q = 0; q < nslot; ++q)
-      best = resolve_slot_block(lds, xrow, n, listed ? (unsigned)lds->slow[q] : q, ternary, best);
+    for (unsigned q = 0; q < nslot; q += kBlkSlots)
+      best = resolve_slots_block(lds, xrow, n, min((unsigned)kBlkSlots, nslot - q),
+                                 [&](unsigned j) { return listed ? (unsigned)lds->slow[q + j] : q + j; }, ternary, best);
     round0 += kSlotCap;
     if (round0 >= tflag) break;
     l1_scan(lds, n, round0, ternary, bin_lo, bin_hi);
