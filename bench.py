@@ -188,19 +188,33 @@ def config_leg(tag, model, x, steps, warmup, workload, cpu_reference_img_s=None)
 def cpu_baseline(arch, model, sample):
     """The oracle's whole-network forward (same algorithmic structure as the reference: sort + cumsum +
     mask + [N,K,M] cost + fp32 conv; scripts/cpu_oracle_vs_reference.py times the two side by side in the build
-    container) on this box's host cores, ONE batch of `sample` images as SURVEY 8(d) states (B = 64)."""
+    container) on this box's host cores, ONE batch of `sample` images as SURVEY 8(d) states (B = 64).  Thread count:
+    the faster of 16 and 32 on a two-image probe -- torch's default of half the logical CPUs (128 here) is five times
+    SLOWER on this workload (scripts/cpu_threads.py: 29.5 images/s at 16 threads, 6.0 at 128)."""
     from oracle import ref_models
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(0)
     x = torch.randn(sample, 3, 224, 224, generator=g)
-    with torch.no_grad():
-        ref_models.resnet_forward(sd, arch, x[:2])                      # warm-up (thread pools, allocator)
-        t0 = time.perf_counter()
-        ref_models.resnet_forward(sd, arch, x)
-        dt = time.perf_counter() - t0
-    return {'value': sample / dt, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'one eval forward of a batch of {sample} images of the same workload ({dt:.1f} s), '
-                      f'host cpu_count={os.cpu_count()}'}
+    before = torch.get_num_threads()
+    try:
+        with torch.no_grad():
+            probe = {}
+            for nt in sorted({min(16, os.cpu_count() or 1), min(32, os.cpu_count() or 1)}):
+                torch.set_num_threads(nt)
+                ref_models.resnet_forward(sd, arch, x[:2])              # warm-up (thread pools, allocator)
+                t0 = time.perf_counter()
+                ref_models.resnet_forward(sd, arch, x[:4])
+                probe[nt] = time.perf_counter() - t0
+            threads = min(probe, key=probe.get)
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            ref_models.resnet_forward(sd, arch, x)
+            dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(before)
+    return {'value': sample / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'one eval forward of a batch of {sample} images of the same workload ({dt:.1f} s) on {threads} threads '
+                      f'(the faster of 16 / 32), host cpu_count={os.cpu_count()}'}
 
 
 def main():
