@@ -223,7 +223,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--cpu-sample', type=int, default=64, help='batch of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=256, help='batch of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the legs of the other single-GPU configs')
     ap.add_argument('--act', default='ls-2', choices=['ls-1', 'ls-2', 'ls-T', 'gf-2', 'fp'],
