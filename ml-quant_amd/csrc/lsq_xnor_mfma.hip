@@ -1,25 +1,27 @@
-// Binary x binary 3x3 convolution on the integer matrix cores of gfx950 (v_mfma_i32_32x32x32_i8), for the layers
-// whose whole weight operand fits the register file of a wave: C = 64 (72 VGPRs of weights per 32 out-channels).
-// Second implementation of F.conv2d(x_q, w_q, ...) of quant/binary/binary_conv.py:165-173 next to the popcount
-// kernel (lsq_xnor_conv.hip); same operands, same epilogue arithmetic, bit-identical output.
+// Binary x binary 3x3 convolution on the integer matrix cores of gfx950 (v_mfma_i32_32x32x32_i8) for 64, 128, 256
+// and 512 input channels -- all sixteen quantized layers of ResNet-18.  Second implementation of
+// F.conv2d(x_q, w_q, ...) of quant/binary/binary_conv.py:165-173 next to the popcount kernel (lsq_xnor_conv.hip, every
+// other geometry): same operands, same epilogue arithmetic, bit-identical output (tests/test_gpu_parity.py).
 //
-// Why only these layers, and why it wins there: the popcount kernel spends two VALU instructions per 32 binary
-// MACs and, with 64 channels, 38 % of its instructions outside the popcount core.  The matrix cores do 32768 MACs
-// per instruction, but only if their operands arrive as bytes -- the earlier attempt (bits expanded through an LDS
-// table into an im2col patch, both operands read from LDS) was fed at a third of the rate it needed.  Here
-//   * the WEIGHTS are expanded once per workgroup and stay in registers for its whole life (weight-stationary:
-//     every wave walks many pixel tiles with the same 9 x 2 operand fragments);
+// The popcount kernel spends two VALU instructions per 32 binary MACs (v_bcnt at half rate: 688 T MAC/s at best) and,
+// with 64 channels, 38 % of its instructions outside the popcount core.  The matrix cores do 32768 MACs per
+// instruction, but want bytes; a first attempt (bits expanded through an LDS table into an im2col patch, both
+// operands read from LDS) was fed at a third of the rate it needed.  What makes this one work:
 //   * the ACTIVATION operand is built from the packed word in registers with ONE v_and_b32 per four channels:
 //     an MFMA sums over k in any order as long as both operands agree on it, so k-slot (register q, byte b) of a
 //     lane is defined as channel q + 8 b of the lane's 32-bit half of the word, and `word & (0x01010101 << q)`
 //     IS that register -- its bytes hold 0 or 2^q.  The weight byte of the same slot is +-(64 >> q), so every
 //     product is +-64 or 0 and the accumulator is 64 * sum_c s_c [b_c = +1], an exact integer.  (q = 7 would be
 //     the sign bit of an int8: that register is `(word >> 7) & 0x01010101` against weights of +-64.)
-//   * no LDS and no barrier inside the tile loop; the words of the next tile are requested before this tile's
-//     MFMAs (the popcount kernel's access pattern: lanes = consecutive pixels = consecutive words).
-//
-// (b * s) = 2 * sum_c s_c [b_c = +1] - sum_c s_c over the taps inside the image; halo words are zero bits and
-// contribute nothing to the first term, the second comes from the same wsum tables as the popcount kernel.
+//   * the WEIGHTS are expanded once per workgroup (six VALU instructions per register) into LDS, 1 KB per (word, tap,
+//     half) fragment, and streamed from there through a ring of three register fragments, two taps ahead; all waves
+//     of a workgroup work on the same 32 out-channels and stride over its pixel tiles;
+//   * no LDS patch and no barrier inside the tile loop: a lane loads the dword of ITS pixel and ITS half of the word
+//     straight from the bit planes (the popcount kernel's coalesced access pattern), one channel word ahead of the
+//     MFMAs that consume it; scheduling barriers pin the order of issue;
+//   * the epilogue has no integer work: (b * s) = 2 * sum_c s_c [b_c = +1] - sum over the taps inside the image of
+//     sum_c s_c; the second term depends only on the pixel's border pattern (a 4 KB table per workgroup) and is
+//     loaded into the accumulators, times 32, before the first MFMA.  Residuals and scales are requested a tile ahead.
 //
 // Tile = 32 consecutive output pixels (flat over n, ho, wo) x 32 out-channels per wave; D[o][pixel]: a lane holds
 // ONE pixel (column lane & 31) and 16 out-channels (rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
@@ -34,11 +36,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr unsigned kM0 = 0x01010101u;
 
-// WREG: the weight fragments live in registers (GG = 1: 72 VGPRs); otherwise they are re-read from LDS for every
-// tile (conflict-free ds_read_b128, a quarter to a half of the LDS bandwidth at full MFMA rate).
+// The weight fragments are re-read from LDS for every tile (conflict-free ds_read_b128 at 256 B/clk: a quarter of the
+// LDS bandwidth at full MFMA rate); keeping the 72 VGPRs of the 64-channel case in registers instead measured slower
+// once the epilogue inputs were requested early (fewer waves per SIMD).
 // NWAVES: waves per workgroup, all on the same 32 out-channels (8 when the fragments of 512 channels fill the LDS of
 // a CU: one workgroup per CU, still two waves per SIMD).
-template <int KX, int GG, int TAPS, bool WREG, int NWAVES, int WPC>
+template <int KX, int GG, int TAPS, int NWAVES, int WPC>
 __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
   constexpr int NT = 64 * NWAVES;
   constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (word, tap, half of the dword's bits)
@@ -152,23 +155,16 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     s_fc[bh][bw][o] = (short)v;
   }
   __syncthreads();
-  v4i wreg[WREG ? NF : 1];
-  if (WREG) {
-#pragma unroll
-    for (int f = 0; f < NF; ++f) wreg[f] = s_w[f][lane];
-  }
 
   if (!have_tile) return;
 
   // ---- tiles ------------------------------------------------------------------------------------------------------
   constexpr int kRing = 3;                       // weight fragments of kRing consecutive (word, tap) steps; 9 GG % kRing == 0
   v4i wring[kRing][2];
-  if (!WREG) {
 #pragma unroll
-    for (int i = 0; i < kRing - 1; ++i) {
-      wring[i][0] = s_w[2 * i][lane];
-      wring[i][1] = s_w[2 * i + 1][lane];
-    }
+  for (int i = 0; i < kRing - 1; ++i) {
+    wring[i][0] = s_w[2 * i][lane];
+    wring[i][1] = s_w[2 * i + 1][lane];
   }
   for (;;) {
     const int nxt = tile + tstride;
@@ -239,19 +235,16 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       unsigned xn[NW];
       if (j + 1 < GG) request(cur, j + 1, xn);
       else if (more) request(nx, 0, xn);
-      if (!WREG) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         constexpr int kAll = GG * TAPS;
         const int idx = j * TAPS + t;
-        if (!WREG) {
-          const int pre = (idx + kRing - 1) % kAll;
-          wring[(idx + kRing - 1) % kRing][0] = s_w[2 * pre][wl];
-          wring[(idx + kRing - 1) % kRing][1] = s_w[2 * pre + 1][wl];
-          __builtin_amdgcn_sched_barrier(0);       // reads first: they must not sink below this step's MFMAs
-        }
-        const v4i w0 = WREG ? wreg[WREG ? 2 * idx : 0] : wring[idx % kRing][0];
-        const v4i w1 = WREG ? wreg[WREG ? 2 * idx + 1 : 0] : wring[idx % kRing][1];
+        const int pre = (idx + kRing - 1) % kAll;
+        wring[(idx + kRing - 1) % kRing][0] = s_w[2 * pre][wl];
+        wring[(idx + kRing - 1) % kRing][1] = s_w[2 * pre + 1][wl];
+        __builtin_amdgcn_sched_barrier(0);         // reads first: they must not sink below this step's MFMAs
+        const v4i w0 = wring[idx % kRing][0], w1 = wring[idx % kRing][1];
         v4i b0[KX], b1[KX];
 #pragma unroll
         for (int p = 0; p < KX; ++p) {
@@ -269,7 +262,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
         for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0[p], acc[p], 0, 0, 0);
 #pragma unroll
         for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1[p], acc[p], 0, 0, 0);
-        if (!WREG) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (j + 1 < GG || more) {
 #pragma unroll
@@ -336,7 +329,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
   long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
   if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
-  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, false, NWAVES, WPC>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
 }
 
