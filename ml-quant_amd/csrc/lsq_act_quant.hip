@@ -1,9 +1,12 @@
-// Activation quantization for gfx950: clamp -> per-row optimal-scale solve -> packed sign planes.
+// Activation quantization for gfx950: clamp -> per-row optimal-scale solve -> packed sign planes.  This file holds
+// the entry point lsq_act_quant, the single-sweep schemes (ls-1, gf-k, forced scales) and the STREAMING solver;
+// the ls-2 / ls-T solve of the reference's skip = 3 sub-sample -- the hot configuration -- runs as one launch of
+// aq_fused_kernel (lsq_act_fused.hip) and comes here only when that kernel does not take the shape (row length not
+// a multiple of 4, fewer than 4 pixels, other skips, more than 2^22 keys) or under lsq_debug_force_streaming.
 //
-// One 1024-thread workgroup owns one row (one sample, quantization.py:77) in every kernel of the sequence
-// (histogram sweep -> solve -> one sweep per further plane); rows are independent, so a batch of N rows is
-// a grid of N workgroups.  The kernels are separate on purpose: each gets its own register allocation
-// (fused into one kernel, the rarely used paths pushed the streaming loops into scratch).
+// Streaming path: one 1024-thread workgroup owns one row (one sample, quantization.py:77) in every kernel of the
+// sequence (histogram sweep -> solve -> one sweep per further plane); rows are independent, so a batch of N rows is
+// a grid of N workgroups.  The kernels are separate so that each gets its own register allocation.
 //
 // The optimal-v1 solve (quant/binary/optimal.py:41-155) never sorts.  It is a radix select over the IEEE
 // bit pattern of |x|: a 13-bit level-1 histogram over the whole sub-sample, then, for the few bins that can
@@ -14,11 +17,11 @@
 // are monotone in the sorted position i, so only bins whose value range can intersect them are refined
 // (typically 10-25 of 8192); their keys are gathered once into LDS.  Candidates are tested exactly (fp64)
 // and their least-squares cost is evaluated in closed form from the prefix sums, replacing the reference's
-// [N,K,M] broadcast (optimal.py:31-38).  oracle/radix_select_model.py is the host model of this file.
+// [N,K,M] broadcast (optimal.py:31-38).  The arithmetic shared with the fused kernel is in lsq_solver_math.h.
 //
-// Memory traffic per row of M floats: the histogram sweep reads M (plane 0 + level-1 histogram), the
-// solve's gather reads M again (the sub-sample touches every line at skip = 3), the plane-1 sweep reads M
-// (plane 1 + v2).  Writes are M/8 bytes per plane.  Algorithmic minimum is one read of M.
+// Memory traffic per row of M floats (streaming path): the histogram sweep reads M (plane 0 + level-1 histogram),
+// the solve's gather reads M again (the sub-sample touches every line at skip = 3), the plane-1 sweep reads M
+// (plane 1 + v2).  Writes are M/8 bytes per plane.  The fused kernel reads M twice.
 
 #include <type_traits>
 

@@ -23,11 +23,11 @@
 // K = (kh, c, kw) with kw padded 7 -> 8 so that the 8 k-values of one MFMA operand register group are EIGHT
 // CONSECUTIVE INPUT COLUMNS of one (kh, c) input row: K = 7 * 3 * 8 = 168 -> 11 steps of 16 (two input rows per
 // step; the 22nd row has zero weights).  The pad slot sits in FRONT (k = 0 is column 2x - 4, a zero weight), which
-// makes the operand start at an even bf16 index: four aligned ds_read_b32 per operand, conflict-free across the
+// makes the operand start at an even 16-bit index: two ds_read2_b32 per operand, conflict-free across the
 // 32 lanes (consecutive pixels = consecutive dwords).
 //
 // One 256-thread workgroup = one image x four pooled rows (nine conv rows: one halo row recomputed), walked in
-// chunks of 32 conv columns.  Per chunk: stage the 23 x 72 input patch of the three channels as bf16 hi / lo
+// chunks of 32 conv columns.  Per chunk: stage the 23 x 72 input patch of the three channels as 16-bit term
 // planes in LDS; wave w owns out-channel tile w / 2 and conv rows w % 2, w % 2 + 2, ...: 66 (33) MFMAs per
 // row on two accumulators (leading products, cross terms); the three row-neighbours of each pixel are combined with two
 // cross-lane moves (horizontal 3-max, stride 2; the column left of the chunk comes from an LDS carry written by
