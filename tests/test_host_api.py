@@ -380,3 +380,29 @@ def test_reference_checkpoint_moving_average_inference(golden, tag):
         y = model(x)
     ref = g[tag + '_logits']
     assert y.shape == ref.shape and torch.allclose(y, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_fused_forward_cpu_composition_with_prelu_and_identity():
+    """QuantConv2d.fused_forward off the GPU is the plain composition of the modules it stands for, for every
+    non-linearity of non_linearity_map; blocks report which of them the fused path takes."""
+    import quant.models.resnet as R
+    from quant.binary.binary_conv import QuantConv2d
+    clamp = {'kind': 'symmetric', 'alpha': 2}
+    conv = QuantConv2d('ls-2', 'ls-1', 8, 12, 3, clamp, padding=1)
+    detgen.fill_module(conv, seed=3)
+    bn = torch.nn.BatchNorm2d(8).eval()
+    conv.train()
+    x = detgen.normal('host.fused.x', (2, 8, 6, 6))
+    with torch.no_grad():
+        conv(x)
+    conv.eval()
+    res = detgen.normal('host.fused.r', (2, 12, 6, 6))
+    slope = torch.tensor([0.3])
+    with torch.no_grad():
+        base = conv(bn(x))
+        assert torch.equal(conv.fused_forward(x, bn, res_pre=res, prelu=slope), torch.nn.functional.prelu(base + res, slope))
+        assert torch.equal(conv.fused_forward(x, bn, relu=True, res_post=res), torch.relu(base) + res)
+        assert torch.equal(conv.fused_forward(x, bn), base)
+    assert R._act_args(torch.nn.ReLU()) == {'relu': True} and R._act_args(torch.nn.Identity()) == {}
+    p = torch.nn.PReLU()
+    assert R._act_args(p)['prelu'] is p.weight and R._act_args(torch.nn.Sigmoid()) is None
