@@ -273,7 +273,9 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
     act, slope = _act(relu, prelu, geom.O)
     m = geom.C * geom.H * geom.W
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
-    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel(), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}'):   # planes read + fp32 output written
+    nres = (res_pre is not None) + (res_post is not None)
+    # algorithmic bytes: planes read + fp32 output written + every residual operand of the fused epilogue read
+    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}'):
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
@@ -286,7 +288,8 @@ def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: to
     x = _f32c(x)
     act, slope = _act(relu, prelu, geom.O)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
-    with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel(), flops):     # fp32 input read + fp32 output written
+    nres = (res_pre is not None) + (res_post is not None)
+    with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel() * (1 + nres), flops):     # fp32 input read + fp32 output written + residuals read
         check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), None if pre is None else pre[0].data_ptr(),
                                      None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wscales.shape[0],
                                      wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope), ptr(res_pre),
