@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 5
+#define LSQ_ABI_VERSION 6
 
 /* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
 #define LSQ_ACT_NONE 0
@@ -156,12 +156,24 @@ int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
  * Full-precision activation x sign-weight convolution on bf16 MFMA (x split hi+lo):
  *   y[n][o] = bias[o] + sum_q ws[q][o] * conv(clamp(x), wplane_q)[n][o]
  * Replaces F.conv2d(x, w_q, ...) of binary_conv.py:165-173 when x_quant == 'fp'.
+ *   wprep   NULL, or the buffer lsq_signw_prepare_weight filled for the same wbits / geometry: 9-tap kernels
+ *           (3x3) then take the fast path, whose workgroups copy ready-made bf16 +-1 fragments instead of
+ *           expanding the sign bits again in every workgroup.  Results are identical with and without it.
  */
 int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, const float* pre_shift,
-                     const uint64_t* wbits, int kw_planes,
+                     const uint64_t* wbits, const void* wprep, int kw_planes,
                      const float* wscales, const float* bias, const lsq_conv_geom* g,
                      int act, const float* act_slope, const float* res_pre, const float* res_post,
                      float* y, void* stream);
+
+/*
+ * Once per eval session, next to lsq_pack_weight (the eval branch of WeightQuantizer*.forward,
+ * quant/binary/weight_quantization.py:32-34): the sign planes expanded to the bf16 operand image of
+ * lsq_signw_conv2d's fast path.  lsq_signw_weight_bytes = size of that buffer in bytes, 0 when the
+ * geometry has no fast path (kernels other than 9 taps, groups, channels not a multiple of 16).
+ */
+int64_t lsq_signw_weight_bytes(const lsq_conv_geom* g, int kw_planes);
+int lsq_signw_prepare_weight(const uint64_t* wbits, int kw_planes, const lsq_conv_geom* g, void* wprep, void* stream);
 
 /*
  * Stem tail in front of the first quantized convolution:

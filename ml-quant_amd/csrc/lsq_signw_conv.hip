@@ -16,52 +16,11 @@
 // at precomputed addresses -- each input element is loaded and converted once per workgroup instead of
 // once per tap.  signw_conv_tiled (fall-back): im2col staging per (tap, 32-channel chunk).
 
-#include "lsq_common.h"
+#include "lsq_signw_conv.h"
 
 namespace lsq {
+namespace signw {
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-struct SwArgs {
-  const float* x;                      // [N][C][H][W]
-  const unsigned long long* wbits;     // [taps][Gg][Opad]  (one weight plane)
-  const float* wscale;                 // [O]
-  const float* bias;                   // [O] or null
-  const float* pre_scale;              // [C] or null (folded eval batch norm)
-  const float* pre_shift;
-  float* y;                            // [N][O][Ho][Wo]
-  float alpha;
-  int N, C, H, W, O, KH, KW, sh, sw, ph, pw, dh, dw;
-  int Gg, Ho, Wo, cg, og, og_pad, opad_total, tiles_per_group;
-  int accumulate;
-  int final_pass;
-  int relu;                            // epilogue: y = act(conv + bias + res_pre) + res_post; LSQ_ACT_*
-  const float* slope;                  // PReLU slope(s): [1] or [O]
-  const float* res_pre;                // [N][O][Ho][Wo] or null
-  const float* res_post;
-};
-
-union Frag {
-  unsigned u[4];
-  bf16x8 v;
-};
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-
-// x = hi + lo in bf16: hi = bf16(x) (v_cvt_pk_bf16_f32, round to nearest even), lo = bf16(x - hi).
-// x - hi is exact in fp32, so |x - hi - lo| <= 2^-18 |x|.
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const f32x2 v = {x0, x1};
-  const bf16x2 h = __builtin_convertvector(v, bf16x2);
-  const f32x2 r = v - __builtin_convertvector(h, f32x2);
-  const bf16x2 l = __builtin_convertvector(r, bf16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Tiled (im2col) version: a 256-thread workgroup computes BM out-channels x 128 pixels.  Per K-chunk (one tap,
@@ -79,76 +38,6 @@ constexpr int kBN = 128;                        // pixels per block
 #define LSQ_SIGNW_LDS_BUFS 1
 #endif
 constexpr int kLdsBufs = LSQ_SIGNW_LDS_BUFS;    // 2: one barrier per chunk; 1: two barriers, half the LDS, more blocks per CU
-
-// Epilogue shared by both kernels: lane = pixel column, registers = out-channel rows (coalesced 128-byte
-// stores); y = relu(u * acc + bias|y + res_pre) + res_post on the last weight plane.  Off = unsigned when
-// the host has checked 4*N*O*Ho*Wo < 2^32 (one vector add per output address), else size_t.
-template <typename Off, int BM, int BN, int TM, int TN>
-__device__ __forceinline__ void store_tiles(const SwArgs& a, const f32x16 (&acc)[TM][TN], int t, int o0,
-                                              int wm, int wn, int col, int kh8) {
-  const int HoWo = a.Ho * a.Wo;
-  const long long total = (long long)a.N * HoWo;
-  Off pbase[TN];                                       // byte offset of (n, out-channel o0 + 4*kh8, pixel)
-  bool pok[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const long long pix = (long long)blockIdx.x * BN + (wn * TN + j) * 32 + col;
-    pok[j] = pix < total;
-    const int n = pok[j] ? (int)(pix / HoWo) : 0;
-    const int r = pok[j] ? (int)(pix - (long long)n * HoWo) : 0;
-    pbase[j] = (Off)4 * ((Off)(n * a.O + o0 + 4 * kh8) * (Off)HoWo + (Off)r);
-  }
-  char* yb = reinterpret_cast<char*>(a.y);
-  const char* rpre = reinterpret_cast<const char*>(a.res_pre);
-  const char* rpost = reinterpret_cast<const char*>(a.res_post);
-  const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {
-      // batch of 8 out-channel rows x TN pixel tiles: every load of the batch (previous partial sum,
-      // residuals, scale, bias) is issued before the first use -- a load consumed right after it is issued
-      // costs one memory latency per output
-      float ws[8], bs[8], sl[8], prev[8][TN], r1[8][TN], r2[8][TN];
-      Off yo[8][TN];
-      bool ok[8][TN];
-#pragma unroll
-      for (int qq = 0; qq < 8; ++qq) {
-        const int q = qh * 8 + qq;
-        const int olu = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2);      // wave-uniform part of the row
-        const int ol = olu + 4 * kh8;                                     // C/D layout of the 32x32 MFMA
-        const bool rok = t * BM + ol < a.og;
-        const int o = o0 + (rok ? ol : 0);
-        ws[qq] = a.wscale[o];
-        bs[qq] = (!a.accumulate && a.bias) ? a.bias[o] : 0.f;
-        sl[qq] = (a.final_pass && a.relu >= LSQ_ACT_PRELU) ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o] : 0.f;
-        const Off rowoff = (Off)4 * (Off)olu * (Off)HoWo;                 // scalar
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          ok[qq][j] = rok && pok[j];
-          yo[qq][j] = ok[qq][j] ? pbase[j] + rowoff : (Off)0;
-          prev[qq][j] = a.accumulate ? *reinterpret_cast<const float*>(yb + yo[qq][j]) : 0.f;
-          r1[qq][j] = want_pre ? *reinterpret_cast<const float*>(rpre + yo[qq][j]) : 0.f;
-          r2[qq][j] = want_post ? *reinterpret_cast<const float*>(rpost + yo[qq][j]) : 0.f;
-        }
-      }
-#pragma unroll
-      for (int qq = 0; qq < 8; ++qq) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float out = (a.accumulate ? prev[qq][j] : bs[qq]) + acc[i][j][qh * 8 + qq] * ws[qq];
-          if (a.final_pass) {
-            out += r1[qq][j];
-            if (a.relu == LSQ_ACT_RELU) out = fmaxf(out, 0.f);
-            else if (a.relu >= LSQ_ACT_PRELU) out = out > 0.f ? out : sl[qq] * out;
-            out += r2[qq][j];
-          }
-          if (ok[qq][j]) *reinterpret_cast<float*>(yb + yo[qq][j]) = out;
-        }
-      }
-    }
-  }
-}
 
 template <int BM, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
@@ -288,7 +177,7 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
     __syncthreads();
   }
 
-  store_tiles<size_t, BM, kBN, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
+  store_tiles<size_t, BM, kBN, TM, TN>(a, acc, blockIdx.x, t, o0, wm, wn, col, kh8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,11 +199,8 @@ __global__ __launch_bounds__(256) void signw_conv_tiled(SwArgs a) {
 // chunk i and consumed after it.  Rows have no padding: the two 16-byte halves of row r are swapped when
 // bit 3 of r is set, which makes any 16 consecutive rows hit 16 distinct 4-bank groups.
 // Each wave owns a 64 x 64 tile (2 x 2 MFMA tiles): 16 MFMAs per tap against 6 fragment reads.
-constexpr int kPC = 16;                          // channels per chunk
-constexpr int kPRow = 32;                        // bytes per LDS row (16 bf16)
 constexpr int kTapGroup = 9;                     // taps whose weights are resident at a time
 
-__device__ __forceinline__ int swz(int row, int half) { return row * kPRow + ((half ^ ((row >> 3) & 1)) << 4); }
 
 // PMAX: patch entries the LDS planes hold; PREMAX: channels per group the folded-batch-norm table holds.
 // Stride 1: 128 x 128 (or 64 x 256) tiles, 64 x 64 per wave, PMAX 512.  Stride 2: only every second entry of a
@@ -592,16 +478,30 @@ __global__ __launch_bounds__(256) void signw_conv_patch(SwArgs a, int Hp, int Wp
     }
     __syncthreads();                                     // every wave is done reading before LDS is rewritten
   }
-  store_tiles<unsigned, BM, BN, TM, TN>(a, acc, t, o0, wm, wn, col, kh8);
+  store_tiles<unsigned, BM, BN, TM, TN>(a, acc, blockIdx.x, t, o0, wm, wn, col, kh8);
 }
 
 }  // namespace
+}  // namespace signw
 }  // namespace lsq
 
 using namespace lsq;
+using namespace lsq::signw;
+
+extern "C" int64_t lsq_signw_weight_bytes(const lsq_conv_geom* g, int kw_planes) {
+  if (check_geom(g) || kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return 0;
+  return lean_weight_bytes(g, kw_planes);
+}
+
+extern "C" int lsq_signw_prepare_weight(const uint64_t* wbits, int kw_planes, const lsq_conv_geom* g, void* wprep, void* stream) {
+  if (!wbits || !wprep) return LSQ_E_NULL;
+  if (int e = check_geom(g)) return e;
+  if (kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
+  return lean_prepare(wbits, kw_planes, g, wprep, (hipStream_t)stream);
+}
 
 extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* pre_scale, const float* pre_shift,
-                                const uint64_t* wbits, int kw_planes, const float* wscales, const float* bias,
+                                const uint64_t* wbits, const void* wprep, int kw_planes, const float* wscales, const float* bias,
                                 const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
                                 const float* res_post,
                                 float* y, void* stream) {
@@ -656,6 +556,12 @@ extern "C" int lsq_signw_conv2d(const float* x, float clamp_alpha, const float* 
     a.accumulate = q ? 1 : 0;
     a.final_pass = q == kw_planes - 1 ? 1 : 0;
     const unsigned otiles = (unsigned)(g->groups * a.tiles_per_group);
+    // 3x3 fast path on the weights expanded by lsq_signw_prepare_weight (lsq_signw_lean.hip)
+    const int fast = lean_launch(a, wprep, q, g, st);
+    if (fast != LSQ_E_UNSUPPORTED) {
+      if (fast) return fast;
+      continue;
+    }
     if (use_patch) {
       dim3 grid((unsigned)((total + pbn - 1) / pbn), otiles);
       const bool many = g->KH * g->KW > kTapGroup;

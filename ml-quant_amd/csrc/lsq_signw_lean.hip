@@ -1,0 +1,646 @@
+// Full-precision activation x sign-weight convolution, 9-tap fast path (every 3x3 layer of the reference's ResNets).
+//
+// Same arithmetic as signw_conv_patch (lsq_signw_conv.hip): implicit GEMM over k = (tap, channel) on
+// v_mfma_f32_32x32x16_bf16 with x = hi + lo (two bf16 terms), fp32 accumulation -- bit-identical output
+// (tests/test_gpu_parity.py); replaces F.conv2d(x, w_q, ...) of quant/binary/binary_conv.py:165-173 for x_quant == 'fp'.
+// What differs is everything around the matrix core.  Measured on the general kernel (round 3, profiles/r03_signw_*):
+// ten VALU and nine scalar instructions per MFMA (weight-bit expansion, per-item branches, address arithmetic), and
+// -- the larger part -- a vector-memory pipe saturated by 4-byte accesses: every dword load / store costs a full
+// 16-cycle address pass, so the fp32 patch of one 16-channel chunk (32 KB) took 2000 cycles of the CU's load path and
+// the epilogue's row-per-register stores as long again.  Here
+//   * the +-1 weights are expanded to bf16 ONCE per eval session (lean_prepare) into the very byte image the
+//     workgroups keep in LDS: staging them is 16-byte loads and 16-byte LDS stores, no arithmetic;
+//   * the input is loaded 16 bytes per lane: a conversion item = 4 consecutive floats of one image plane x 8 channels
+//     (eight loads, lane offset fixed for the whole tile, channel base in scalar registers), every float mapped to
+//     its own row of the LDS patch (halo rows are never written and stay zero); five VALU instructions per element:
+//     folded batch norm (fma), clamp (med3), bf16 hi / lo split;
+//   * the MFMA roles are A = activations, B = weights, so a lane of the accumulator owns ONE out-channel and groups
+//     of FOUR CONSECUTIVE PIXELS: residual loads and output stores are 16 bytes per lane too, and the per-channel
+//     scale / bias / slope are per-lane constants;
+//   * workgroups are persistent: a workgroup walks over its (pixel tile, out-channel tile) units, the stores of one
+//     unit drain while the next one computes, and the first loads of the next unit are issued before the last
+//     chunk's MFMAs of the current one; all index arithmetic uses host-made multiply-shift divisors.
+// One workgroup = 4 waves = 64 out-channels x (128 TN) pixel slots, 16 channels (one MFMA k-step) per stage; two
+// workgroups per CU.  Units are numbered XCD-major so that neighbouring pixel tiles (which share halo rows) and the
+// out-channel tiles of one pixel tile (which share the whole patch) run on the same XCD's L2 at the same time.
+
+#include "lsq_signw_conv.h"
+
+namespace lsq {
+namespace signw {
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTaps = 9;
+
+#ifdef LSQ_SIGNW_CLOCKS
+// developer build (scripts/signw_clocks.py): per workgroup, hardware ids and s_memtime stamps of its first unit
+__device__ unsigned long long* g_signw_clk = nullptr;
+#define LSQ_CLK(slot_)                                                                            \
+  do {                                                                                            \
+    if (clk && unit_no == LSQ_SIGNW_CLOCKS && tid == 0 && (slot_) < 64) clk[slot_] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define LSQ_CLK(slot_) do { } while (0)
+#endif
+constexpr int kLeanBM = 64;
+constexpr int kLeanMaxPre = 512;                 // channels the folded-batch-norm table holds
+constexpr int kMaxItems = 2;                     // conversion items (4 pixels x 8 channels) per thread and chunk
+constexpr int kWStage = kTaps * kLeanBM * kPRow; // bytes of expanded weights per (out-channel tile, chunk): 18 KB
+
+// n / d for 0 <= n < 2^31 as a multiply-high and a shift (d = 1: mul == 0)
+struct FastDiv {
+  unsigned mul, shift;
+};
+__device__ __forceinline__ int fdiv(int n, FastDiv d) {
+  return d.mul ? (int)(__umulhi((unsigned)n, d.mul) >> d.shift) : n;
+}
+FastDiv make_fastdiv(long long d) {
+  FastDiv f = {0u, 0u};
+  if (d <= 1) return f;
+  int L = 0;
+  while ((1ll << L) < d) ++L;                    // 2^(L-1) < d <= 2^L
+  const int p = 31 + L;
+  f.mul = (unsigned)((((__int128)1 << p) + d - 1) / d);     // ceil(2^p / d) < 2^32
+  f.shift = (unsigned)(p - 32);
+  return f;
+}
+
+struct LeanGeo {
+  int Hp, Wp, n_otiles, opad64;
+  int S;                                         // pixel slots per image: Ho * Wo rounded up to a multiple of 4
+  int n_units;                                   // pixel tiles x out-channel tiles
+  int stagger;                                   // start delay of the workgroup in the odd wave slot, in 4096-cycle steps
+  FastDiv dS, dWo, dHpWp, dWp, dHW, dGPI, dW, dOt;
+};
+
+// Expanded weights: [plane][chunk][tap][O padded to 64][32 bytes], row o = 16 bf16 +-1 of channels 16 chunk .. +15 with
+// the two 16-byte halves swapped when bit 3 of o is set (the LDS image of swz()); rows past O are zero.
+__global__ __launch_bounds__(256) void lean_expand_kernel(const unsigned long long* __restrict__ wbits, uint4* __restrict__ out,
+                                                           int planes, long long plane_words, int cchunks, int Gg,
+                                                           int opad16, int O, int opad64) {
+  const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long rows = (long long)planes * cchunks * kTaps * opad64;
+  if (row >= rows) return;
+  const int o = (int)(row % opad64);
+  long long r = row / opad64;
+  const int tap = (int)(r % kTaps);
+  r /= kTaps;
+  const int cc = (int)(r % cchunks), q = (int)(r / cchunks);
+  unsigned d[8];
+  if (o < O) {
+    const int c0 = cc * kPC;
+    const unsigned long long w = wbits[q * plane_words + ((long long)tap * Gg + (c0 >> 6)) * opad16 + o];
+    const unsigned bits = (unsigned)(w >> (c0 & 63)) & 0xFFFFu;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const unsigned b0 = (bits >> (2 * p)) & 1u, b1 = (bits >> (2 * p + 1)) & 1u;     // set = +1
+      d[p] = 0x3F803F80u | ((b0 ^ 1u) << 15) | ((b1 ^ 1u) << 31);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) d[p] = 0u;
+  }
+  const int s = (o >> 3) & 1;
+  out[2 * row + s] = make_uint4(d[0], d[1], d[2], d[3]);
+  out[2 * row + (s ^ 1)] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+// LDS patch rows.  Logical entry e (padded linear position relative to the tile's first one) lives in physical
+// row p(e) = e with the two low bit pairs swapped inside every block of 16, and the 16-byte half h of a row sits at
+// (h ^ bit 3 of p):
+//   * fragment reads (ds_read_b128, 16 lanes per LDS cycle on entries whose residues mod 16 are all different --
+//     consecutive pixels) touch each 32-byte slot of the 256-byte bank window twice, once per half: conflict-free;
+//   * the conversion writes the four CONSECUTIVE entries a lane holds one per instruction, so the lanes of one
+//     instruction write entries 4 apart -- physical rows 1 apart: 2-way instead of 8-way.
+__device__ __forceinline__ int prow(int e) { return (e & ~15) | ((e & 3) << 2) | ((e >> 2) & 3); }
+__device__ __forceinline__ int paddr(int e, int half) {
+  const int p = prow(e);
+  return p * kPRow + ((half ^ ((p >> 3) & 1)) << 4);
+}
+
+// Pixel slots: every image owns S = Ho * Wo rounded up to 4 consecutive slots, the last S - Ho * Wo of them empty, so
+// that an aligned group of four slots never straddles two images (16-byte epilogue accesses for 7 x 7 images too).
+// ODD: Ho * Wo is not a multiple of 4 (the last group of an image holds fewer than four pixels).
+template <int TN, int ITEMS, bool ODD>
+__global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsigned char* __restrict__ wexp, LeanGeo geo) {
+  constexpr int BM = kLeanBM, TM = 2, BN = 128 * TN;
+  constexpr int PL = TN == 2 ? 512 : 832;                  // patch entries the LDS planes hold (2 workgroups per CU)
+  constexpr int kPlane = (PL + 16) * kPRow;                // + a block of spare rows: the dump row
+  constexpr int kDump = PL * kPRow;
+  constexpr int kWPieces = kWStage / 16, kWIt = (kWPieces + 255) / 256, kWLast = kWPieces - 256 * (kWIt - 1);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kPlane + kWStage + 2 * kLeanMaxPre * 4];
+  unsigned char* const sP = smem;                          // [hi | lo][PL + 16 rows][32 bytes]
+  unsigned char* const sW = smem + 2 * kPlane;             // [tap][64 rows][32 bytes]
+  float* const sPre = reinterpret_cast<float*>(sW + kWStage);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 31, kh8 = lane >> 5;
+  const int Hp = geo.Hp, Wp = geo.Wp;
+  const int HoWo = a.Ho * a.Wo, HW = a.H * a.W;
+  const int S = geo.S, total = a.N * S;
+  const int cchunks = a.C / kPC;
+  const float lim = a.alpha >= 0.f ? a.alpha : __builtin_inff();   // clamp_identity: no-op bounds
+  const int GPI = (HW + 3) >> 2;                         // conversion groups per image plane
+
+  // Units of this workgroup.  Workgroup b runs on XCD b % 8: XCD x owns the contiguous unit range [x U8, (x + 1) U8)
+  // and its workgroups (j = b / 8) take units j, j + G / 8, ... of it -- adjacent workgroups, adjacent units.
+  const int wg8 = (int)gridDim.x >> 3;                   // workgroups per XCD (the grid is a multiple of 8)
+  const int U8 = (geo.n_units + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int unit_end = min((xcd + 1) * U8, geo.n_units);
+  int unit = xcd * U8 + ((int)blockIdx.x >> 3);
+  if (unit >= unit_end) return;
+
+  // folded batch norm (identity when the caller folds none: x * 1 + 0)
+  for (int c = tid; c < a.C; c += 256) {
+    sPre[c] = a.pre_scale ? a.pre_scale[c] : 1.f;
+    sPre[kLeanMaxPre + c] = a.pre_scale ? a.pre_shift[c] : 0.f;
+  }
+
+  // position (n * Hp + ho * stride) * Wp + wo * stride of pixel slot (n, r), r < Ho * Wo
+  auto base_of = [&](int n, int r) {
+    const int ho = fdiv(r, geo.dWo);
+    return (n * Hp + ho * a.sh) * Wp + (r - ho * a.Wo) * a.sw;
+  };
+
+  // ---- per-unit state
+  int ptile, o0, p0, bmin;
+  unsigned it_voff[ITEMS];                               // byte offset of the item's 4 floats in channel 0 of its image
+  int it_gid[ITEMS], it_oct[ITEMS];
+  bool it_on[ITEMS];                                     // wave-uniform: the wave has an item in round u
+  int it_dst[ITEMS][4];
+  unsigned w_goff[kWIt];
+  int x_addr[kTaps][TN];                                 // hi-plane byte address of the activation fragment
+  float ep_scale[TM], ep_bias[TM], ep_slope[TM];
+
+  // Conversion items of a unit.  The image planes are cut into groups of 4 consecutive floats (the last group of a
+  // plane whose size is not a multiple of 4 starts at HW - 4 and overlaps its predecessor: no load ever leaves the
+  // plane); the groups that hold a pixel of the patch are consecutive in (image, group) order.
+  auto unit_items = [&](int un) {
+    ptile = fdiv(un, geo.dOt);
+    o0 = (un - ptile * geo.n_otiles) * BM;
+    p0 = ptile * BN;
+    // first and last real pixel of the tile
+    int n_f = fdiv(p0, geo.dS), r_f = p0 - n_f * S;
+    if (r_f >= HoWo) { r_f = 0; ++n_f; }                 // (an empty slot: the next image starts the tile)
+    if (n_f >= a.N) { n_f = a.N - 1; r_f = HoWo - 1; }   // (a tile of empty slots only: nothing is stored)
+    const int pl = min(p0 + BN, total) - 1;
+    const int n_l = fdiv(pl, geo.dS), r_l = min(pl - n_l * S, HoWo - 1);
+    bmin = base_of(n_f, r_f);
+    const int bmax = base_of(n_l, r_l) + (a.KH - 1) * a.dh * Wp + (a.KW - 1) * a.dw;   // last position any tap touches
+    auto pixel_at_or_after = [&](int L) {                // dense pixel index n * HW + hi * W + wi of the first image pixel at position >= L
+      int n = fdiv(L, geo.dHpWp);
+      const int rem = L - n * Hp * Wp;
+      const int hp = fdiv(rem, geo.dWp);
+      int hi = hp - a.ph, wi = rem - hp * Wp - a.pw;
+      if (hi < 0) { hi = 0; wi = 0; }
+      if (wi < 0) wi = 0;
+      if (wi >= a.W) { wi = 0; ++hi; }
+      if (hi >= a.H) { hi = 0; wi = 0; ++n; }
+      return n * HW + hi * a.W + wi;
+    };
+    const int q_lo = min(pixel_at_or_after(bmin), a.N * HW - 1);
+    const int q_hi = max(min(pixel_at_or_after(bmax + 1), a.N * HW) - 1, q_lo);     // last image pixel at position <= bmax
+    const int n_lo = fdiv(q_lo, geo.dHW), n_hi = fdiv(q_hi, geo.dHW);
+    const int gid_lo = n_lo * GPI + min((q_lo - n_lo * HW) >> 2, GPI - 1);
+    const int gid_hi = n_hi * GPI + min((q_hi - n_hi * HW) >> 2, GPI - 1);
+    const int count = gid_hi - gid_lo + 1;
+    const int count_pad = (count + 63) & ~63;            // items of octet 0: [0, count_pad), octet 1: [count_pad, 2 count_pad)
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int i = tid + 256 * u;
+      it_on[u] = u == 0 || (tid & ~63) + 256 * u < 2 * count_pad;
+      const int oct = i >= count_pad;
+      const int gi = i - oct * count_pad;
+      const bool active = gi < count;
+      const int gid = gid_lo + (active ? gi : 0);
+      const int n = fdiv(gid, geo.dGPI);
+      const int r0 = min((gid - n * GPI) << 2, HW - 4);
+      it_voff[u] = (unsigned)(n * a.C * HW + r0) * 4u;
+      it_gid[u] = active ? gid : -1;
+      it_oct[u] = __builtin_amdgcn_readfirstlane(oct);
+    }
+#pragma unroll
+    for (int k = 0; k < kWIt; ++k) {
+      const int p = tid + 256 * k;
+      const int tap = p >> 7, r = p & 127;               // 128 pieces per tap
+      w_goff[k] = p < kWPieces ? (unsigned)((tap * geo.opad64 + o0) * kPRow + r * 16) : 0u;   // (past the image: a valid dummy, not stored)
+    }
+  };
+  // LDS addresses of a unit (after unit_items of the same unit)
+  auto unit_tables = [&]() {
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int gid = max(it_gid[u], 0);
+      const int n = fdiv(gid, geo.dGPI);
+      const int r0 = min((gid - n * GPI) << 2, HW - 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k;
+        const int hi = fdiv(r, geo.dW), wi = r - hi * a.W;
+        const int e = (n * Hp + hi + a.ph) * Wp + wi + a.pw - bmin;
+        it_dst[u][k] = (it_gid[u] >= 0 && e >= 0 && e < PL) ? paddr(e, it_oct[u]) : kDump;
+      }
+    }
+    int e_pix[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int p = p0 + (wid * TN + j) * 32 + col;
+      const int n = fdiv(p, geo.dS), r = p - n * S;
+      e_pix[j] = (p < total && r < HoWo) ? base_of(n, r) - bmin : 0;     // (empty slots compute on entry 0 and store nothing)
+    }
+    int kh = 0, kw = 0;
+#pragma unroll
+    for (int tt = 0; tt < kTaps; ++tt) {
+      const int toff = kh * a.dh * Wp + kw * a.dw;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) x_addr[tt][j] = paddr(e_pix[j] + toff, kh8);
+      if (++kw == a.KW) { kw = 0; ++kh; }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {                       // the lane's out-channel in each 32-wide tile
+      const int o = o0 + i * 32 + col;
+      const bool ok = o < a.O;
+      ep_scale[i] = ok ? a.wscale[o] : 0.f;
+      ep_bias[i] = (ok && !a.accumulate && a.bias) ? a.bias[o] : 0.f;
+      ep_slope[i] = (ok && a.final_pass && a.relu >= LSQ_ACT_PRELU) ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o] : 0.f;
+    }
+  };
+
+  f32x4 raw[ITEMS][8];
+  auto issue_xloads = [&](int cc) {
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      if (!it_on[u]) continue;
+      const char* cbase = reinterpret_cast<const char*>(a.x + (long long)(cc * kPC + it_oct[u] * 8) * HW);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        raw[u][j] = *reinterpret_cast<const f32x4*>(cbase + (long long)j * HW * 4 + it_voff[u]);   // 4-byte aligned at least
+    }
+  };
+  auto convert_store = [&](int cc) {
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      if (!it_on[u]) continue;
+      const int c0 = cc * kPC + it_oct[u] * 8;
+      const float4* ps = reinterpret_cast<const float4*>(sPre + c0);                 // wave-uniform: broadcast reads
+      const float4* pb = reinterpret_cast<const float4*>(sPre + kLeanMaxPre + c0);
+      const float4 s0 = ps[0], s1 = ps[1], b0 = pb[0], b1 = pb[1];
+      const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(fmaf(raw[u][j][k], sc[j], sh[j]), -lim, lim);
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_pair(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+        *reinterpret_cast<uint4*>(sP + it_dst[u][k]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4*>(sP + kPlane + it_dst[u][k]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      }
+    }
+  };
+
+  // weight staging: 16-byte pieces of the chunk's [tap][64 rows][32 bytes] image, copied as they are
+  u32x4 wr[kWIt];
+  auto issue_wloads = [&](int cc) {
+    const unsigned char* wbase = wexp + (long long)cc * kTaps * geo.opad64 * kPRow;
+#pragma unroll
+    for (int k = 0; k < kWIt; ++k) wr[k] = *reinterpret_cast<const u32x4*>(wbase + w_goff[k]);
+  };
+  auto store_w = [&]() {
+#pragma unroll
+    for (int k = 0; k < kWIt; ++k)
+      if (k < kWIt - 1 || tid < kWLast) *reinterpret_cast<u32x4*>(sW + (tid + 256 * k) * 16) = wr[k];
+  };
+
+  int w_addr[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) w_addr[i] = swz(i * 32 + col, kh8);
+
+  f32x16 acc[TM][TN];
+  Frag wf[2][TM], xh[2][TN], xl[2][TN];
+  auto load_frags = [&](int tt, int s) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(sW + tt * (BM * kPRow) + w_addr[i]);
+      wf[s][i].u[0] = v.x; wf[s][i].u[1] = v.y; wf[s][i].u[2] = v.z; wf[s][i].u[3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const uint4 vh = *reinterpret_cast<const uint4*>(sP + x_addr[tt][j]);
+      const uint4 vl = *reinterpret_cast<const uint4*>(sP + kPlane + x_addr[tt][j]);
+      xh[s][j].u[0] = vh.x; xh[s][j].u[1] = vh.y; xh[s][j].u[2] = vh.z; xh[s][j].u[3] = vh.w;
+      xl[s][j].u[0] = vl.x; xl[s][j].u[1] = vl.y; xl[s][j].u[2] = vl.z; xl[s][j].u[3] = vl.w;
+    }
+  };
+  auto mfma_tap = [&](int s) {
+    // hi products of all tiles first, then lo: dependent MFMAs on one accumulator are TM * TN apart
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s][j].v, wf[s][i].v, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[s][j].v, wf[s][i].v, acc[i][j], 0, 0, 0);
+  };
+
+  // epilogue arithmetic: the same operations in the same order as the general kernels (store_tiles)
+  const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
+  auto finish = [&](float d, float prev, float r1, float r2, int i) {
+    float out = (a.accumulate ? prev : ep_bias[i]) + d * ep_scale[i];
+    if (a.final_pass) {
+      out += r1;
+      if (a.relu == LSQ_ACT_RELU) out = fmaxf(out, 0.f);
+      else if (a.relu >= LSQ_ACT_PRELU) out = out > 0.f ? out : ep_slope[i] * out;
+      out += r2;
+    }
+    return out;
+  };
+
+#ifdef LSQ_SIGNW_CLOCKS
+  unsigned long long* clk = g_signw_clk ? g_signw_clk + 64ull * blockIdx.x : nullptr;
+  int unit_no = 0;
+  if (clk && tid == 0) {
+    clk[0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_ID
+    clk[1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // XCC_ID
+  }
+#endif
+  unit_items(unit);
+  issue_xloads(0);
+  issue_wloads(0);
+  // The two workgroups of a CU start together and, left alone, stay in lockstep through every unit: both stream the
+  // input (HBM reads only), then both store (HBM writes only, the matrix pipe idle).  The one in the odd wave slot of
+  // its SIMD starts half a unit late: one stores and sets up while the other multiplies.
+  if (geo.stagger > 0 && (__builtin_amdgcn_s_getreg((0 << 11) | (0 << 6) | 4) & 1u))
+    for (int i = 0; i < geo.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  const int ustep = wg8;
+  for (;;) {
+    LSQ_CLK(2);
+    // ---- set-up of the unit, under the flight of its first loads: LDS planes back to zero (the halo entries are never
+    // written), address tables
+    for (int i = tid; i < 2 * kPlane / 16; i += 256) reinterpret_cast<uint4*>(sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+    unit_tables();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int cur_p0 = p0, cur_o0 = o0;
+    const int next = unit + ustep;
+    const bool more = next < unit_end;
+    LSQ_CLK(60);
+    __syncthreads();                                     // zero fill (and, the first time, sPre) visible
+    LSQ_CLK(61);
+    for (int cc = 0; cc < cchunks; ++cc) {
+      LSQ_CLK(4 + 3 * cc);
+      convert_store(cc);
+      store_w();
+      __syncthreads();                                   // patch and weights of this chunk visible
+      LSQ_CLK(5 + 3 * cc);
+      if (cc + 1 < cchunks) {                            // the next chunk's loads fly during the MFMAs below
+        issue_xloads(cc + 1);
+        issue_wloads(cc + 1);
+      } else if (more) {                                 // ... or the first chunk of the NEXT unit
+        unit_items(next);
+        issue_xloads(0);
+        issue_wloads(0);
+      }
+      // fragment reads of tap t + 1 are issued before the MFMAs of tap t (pinned: left alone, the scheduler sinks
+      // them behind the MFMAs into one register set and every tap then starts with an exposed LDS round trip)
+      load_frags(0, 0);
+#pragma unroll
+      for (int tt = 0; tt < kTaps; ++tt) {
+        if (tt + 1 < kTaps) load_frags(tt + 1, (tt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tap(tt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      LSQ_CLK(6 + 3 * cc);
+      __syncthreads();                                   // every wave is done reading before LDS is rewritten
+    }
+    LSQ_CLK(3);
+
+    // ---- epilogue: y = act(scale * acc + bias | y + res_pre) + res_post; register group g of a tile = pixel slots
+    // 8 g + 4 (lane >> 5) + 0..3 of the tile, 16 contiguous bytes of one out-channel.  The stores are not waited for.
+    // (two register groups at a time: the next unit's first loads are in flight and hold their registers)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bool ook[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ook[i] = cur_o0 + i * 32 + col < a.O;
+#pragma unroll
+      for (int gh = 0; gh < 2; ++gh) {
+        unsigned off[2][TM];
+        int nval[2];                                     // real pixels in the group: 4, or fewer at the end of an image
+        f32x4 prev[2][TM], r1[2][TM], r2[2][TM];
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+          const int g = 2 * gh + gl;
+          const int p = cur_p0 + (wid * TN + j) * 32 + 8 * g + 4 * kh8;
+          const int n = fdiv(p, geo.dS), r = p - n * S;
+          nval[gl] = p < total ? min(max(HoWo - r, 0), 4) : 0;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int o = cur_o0 + i * 32 + col;
+            const bool full = nval[gl] == 4 && ook[i];
+            off[gl][i] = (nval[gl] > 0 && ook[i]) ? (unsigned)((n * a.O + o) * HoWo + r) * 4u : 0u;
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const unsigned lo = full ? off[gl][i] : 0u;  // (partial groups read their operands one by one below)
+            prev[gl][i] = a.accumulate ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.y) + lo) : zero;
+            r1[gl][i] = want_pre ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.res_pre) + lo) : zero;
+            r2[gl][i] = want_post ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.res_post) + lo) : zero;
+          }
+        }
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int g = 2 * gh + gl;
+            if (!ODD || nval[gl] == 4) {
+              f32x4 out;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) out[k] = finish(acc[i][j][4 * g + k], prev[gl][i][k], r1[gl][i][k], r2[gl][i][k], i);
+              if (ook[i] && nval[gl] == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + off[gl][i]) = out;
+            } else if (ODD && ook[i]) {                  // end of an image whose size is not a multiple of 4
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                if (k < nval[gl]) {
+                  const unsigned ok4 = off[gl][i] + 4u * k;
+                  const float pv = a.accumulate ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.y) + ok4) : 0.f;
+                  const float q1 = want_pre ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res_pre) + ok4) : 0.f;
+                  const float q2 = want_post ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res_post) + ok4) : 0.f;
+                  *reinterpret_cast<float*>(reinterpret_cast<char*>(a.y) + ok4) = finish(acc[i][j][4 * g + k], pv, q1, q2, i);
+                }
+              }
+            }
+          }
+      }
+    }
+    LSQ_CLK(63);
+#ifdef LSQ_SIGNW_CLOCKS
+    ++unit_no;
+#endif
+    if (!more) break;
+    unit = next;
+  }
+}
+
+template <int TN>
+int launch_items(int items, bool odd, dim3 grid, hipStream_t st, const SwArgs& a, const unsigned char* w, const LeanGeo& geo) {
+  // (instantiated: the combinations that stay inside 256 registers without spilling)
+  if (items == 1) {
+    if (odd) hipLaunchKernelGGL((signw_conv_lean<TN, 1, true>), grid, dim3(256), 0, st, a, w, geo);
+    else hipLaunchKernelGGL((signw_conv_lean<TN, 1, false>), grid, dim3(256), 0, st, a, w, geo);
+  } else if (items == 2 && TN == 1) {
+    if (odd) hipLaunchKernelGGL((signw_conv_lean<1, 2, true>), grid, dim3(256), 0, st, a, w, geo);
+    else hipLaunchKernelGGL((signw_conv_lean<1, 2, false>), grid, dim3(256), 0, st, a, w, geo);
+  } else {
+    return LSQ_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+bool lean_geometry(const lsq_conv_geom* g) {
+  return g->groups == 1 && g->KH * g->KW == kTaps && g->C % kPC == 0 && g->C <= kLeanMaxPre && g->H * g->W >= 4;
+}
+
+// One pass over a period of the tile / image alignment pattern, with the kernel's own arithmetic: the largest patch
+// (padded linear positions between the first and the last one a workgroup's pixels and taps touch) and the largest
+// number of conversion groups (4 consecutive floats of an image plane that hold a pixel of the patch) of any tile.
+struct TileNeeds {
+  long long entries, groups;
+};
+TileNeeds tile_needs(const lsq_conv_geom* g, int Ho, int Wo, int bn) {
+  const int Hp = g->H + 2 * g->pad_h, Wp = g->W + 2 * g->pad_w, HW = g->H * g->W, HoWo = Ho * Wo, HpWp = Hp * Wp;
+  const long long S = (HoWo + 3) / 4 * 4, total = (long long)g->N * S;
+  const long long ntiles = (total + bn - 1) / bn;
+  auto gcd = [](long long x, long long y) { while (y) { const long long t = x % y; x = y; y = t; } return x; };
+  const long long period = S / gcd(S, bn);               // tiles after which the alignment to the images repeats
+  const int GPI = (HW + 3) / 4;
+  TileNeeds worst = {0, 0};
+  if (period > 4096) {                                   // no short period: refuse (the general kernels take the call)
+    worst.entries = worst.groups = 1ll << 40;
+    return worst;
+  }
+  auto base_of = [&](long long n, long long r) {
+    const long long ho = r / Wo;
+    return (n * Hp + ho * g->stride_h) * Wp + (r - ho * Wo) * g->stride_w;
+  };
+  auto pixel_at_or_after = [&](long long L) {
+    long long n = L / HpWp;
+    const long long rem = L - n * HpWp, hp = rem / Wp;
+    long long hi = hp - g->pad_h, wi = rem - hp * Wp - g->pad_w;
+    if (hi < 0) { hi = 0; wi = 0; }
+    if (wi < 0) wi = 0;
+    if (wi >= g->W) { wi = 0; ++hi; }
+    if (hi >= g->H) { hi = 0; wi = 0; ++n; }
+    return n * HW + hi * g->W + wi;
+  };
+  // one period of tiles (all of them when there are fewer); a clipped last tile is never the worst
+  const long long check = ntiles < period + 1 ? ntiles : period + 1;
+  for (long long t = 0; t < check; ++t) {
+    const long long p0 = t * bn;
+    long long n_f = p0 / S, r_f = p0 - n_f * S;
+    if (r_f >= HoWo) { r_f = 0; ++n_f; }
+    if (n_f >= g->N) continue;
+    const long long pl = (p0 + bn < total ? p0 + bn : total) - 1;
+    const long long n_l = pl / S, r_l = (pl - n_l * S < HoWo - 1) ? pl - n_l * S : HoWo - 1;
+    const long long bmin = base_of(n_f, r_f);
+    const long long bmax = base_of(n_l, r_l) + (long long)(g->KH - 1) * g->dil_h * Wp + (long long)(g->KW - 1) * g->dil_w;
+    if (bmax - bmin + 1 > worst.entries) worst.entries = bmax - bmin + 1;
+    const long long q_lo = pixel_at_or_after(bmin);
+    long long q_hi = pixel_at_or_after(bmax + 1);
+    if (q_hi > (long long)g->N * HW) q_hi = (long long)g->N * HW;
+    q_hi -= 1;
+    if (q_hi < q_lo) q_hi = q_lo;
+    const long long n_lo = q_lo / HW, n_hi = q_hi / HW;
+    const long long j_lo = (q_lo - n_lo * HW) >> 2, j_hi = (q_hi - n_hi * HW) >> 2;
+    const long long cnt = n_hi * GPI + (j_hi < GPI - 1 ? j_hi : GPI - 1) - (n_lo * GPI + (j_lo < GPI - 1 ? j_lo : GPI - 1)) + 1;
+    if (cnt > worst.groups) worst.groups = cnt;
+  }
+  return worst;
+}
+
+int items_of(long long groups) {
+  const long long padded = (groups + 63) / 64 * 64;
+  const long long items = (2 * padded + 255) / 256;
+  return (int)(items < 1 ? 1 : items);
+}
+
+}  // namespace
+
+long long lean_weight_bytes(const lsq_conv_geom* g, int planes) {
+  if (!lean_geometry(g)) return 0;
+  const long long opad64 = (g->O + 63) / 64 * 64;
+  return (long long)planes * (g->C / kPC) * kTaps * opad64 * kPRow;
+}
+
+int lean_prepare(const uint64_t* wbits, int planes, const lsq_conv_geom* g, void* wprep, hipStream_t st) {
+  if (!lean_geometry(g)) return LSQ_E_UNSUPPORTED;
+  const int opad64 = (g->O + 63) / 64 * 64, opad16 = (g->O + 15) / 16 * 16;
+  const int cchunks = g->C / kPC, Gg = (g->C + 63) / 64;
+  const long long rows = (long long)planes * cchunks * kTaps * opad64;
+  hipLaunchKernelGGL(lean_expand_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st,
+                     (const unsigned long long*)wbits, (uint4*)wprep, planes, lsq_weight_plane_words(g), cchunks, Gg, opad16,
+                     g->O, opad64);
+  return (int)hipGetLastError();
+}
+
+int lean_launch(const SwArgs& a, const void* wprep, int plane, const lsq_conv_geom* g, hipStream_t st) {
+  if (!wprep || !lean_geometry(g)) return LSQ_E_UNSUPPORTED;
+  const int Hp = g->H + 2 * g->pad_h, Wp = g->W + 2 * g->pad_w;
+  const long long S = ((long long)a.Ho * a.Wo + 3) / 4 * 4;
+  if ((long long)g->N * g->C * g->H * g->W >= (1ll << 30) || (long long)g->N * Hp * Wp + 1024 >= (1ll << 31) ||
+      (long long)g->N * g->O * a.Ho * a.Wo >= (1ll << 30) || (long long)g->N * S + 256 >= (1ll << 31))
+    return LSQ_E_UNSUPPORTED;
+  const int opad64 = (g->O + 63) / 64 * 64, n_otiles = opad64 / 64;
+  // 256 pixel slots per workgroup when their patch fits the 512-row planes and one item per thread (two would
+  // spill at 64 x 64 per wave), else 128 (832 rows, two items)
+  const TileNeeds n256 = tile_needs(g, a.Ho, a.Wo, 256);
+  const bool wide = n256.entries <= 512 && items_of(n256.groups) <= 1;
+  TileNeeds need = n256;
+  if (!wide) {
+    need = tile_needs(g, a.Ho, a.Wo, 128);
+    if (need.entries > 832 || items_of(need.groups) > kMaxItems) return LSQ_E_UNSUPPORTED;
+  }
+  const int bn = wide ? 256 : 128;
+  const int items = items_of(need.groups);
+  const long long ptiles = ((long long)g->N * S + bn - 1) / bn;
+  const long long units = ptiles * n_otiles;
+  if (units >= (1ll << 30)) return LSQ_E_UNSUPPORTED;
+  LeanGeo geo;
+  geo.Hp = Hp; geo.Wp = Wp; geo.n_otiles = n_otiles; geo.opad64 = opad64; geo.S = (int)S; geo.n_units = (int)units;
+  geo.dS = make_fastdiv(S); geo.dWo = make_fastdiv(a.Wo); geo.dHpWp = make_fastdiv((long long)Hp * Wp);
+  geo.dWp = make_fastdiv(Wp); geo.dHW = make_fastdiv((long long)g->H * g->W);
+  geo.dGPI = make_fastdiv(((long long)g->H * g->W + 3) / 4); geo.dW = make_fastdiv(g->W); geo.dOt = make_fastdiv(n_otiles);
+  // half a unit (chunks x ~6500 cycles + set-up and epilogue), when a workgroup has at least three units to walk
+  const long long per_wg = units / 512;
+  geo.stagger = per_wg >= 3 ? (int)(((long long)(g->C / kPC) * 6500 + 24000) / 2 / 4096) : 0;
+#ifdef LSQ_SIGNW_STAGGER
+  geo.stagger = per_wg >= 3 ? LSQ_SIGNW_STAGGER : 0;
+#endif
+  const unsigned char* w = (const unsigned char*)wprep + (long long)plane * (g->C / kPC) * kTaps * opad64 * kPRow;
+  // persistent workgroups: two per CU (256 CUs), a multiple of 8 (one share per XCD)
+  long long wgs = (units + 7) / 8 * 8;
+  if (wgs > 512) wgs = 512;
+  const dim3 grid((unsigned)wgs);
+  const bool odd = (a.Ho * a.Wo) % 4 != 0;
+  return wide ? launch_items<2>(items, odd, grid, st, a, w, geo) : launch_items<1>(items, odd, grid, st, a, w, geo);
+}
+
+}  // namespace signw
+}  // namespace lsq
+
+#ifdef LSQ_SIGNW_CLOCKS
+extern "C" int lsq_debug_signw_clocks(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lsq::signw::g_signw_clk), &buf, sizeof(buf));
+}
+#endif

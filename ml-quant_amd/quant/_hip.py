@@ -17,7 +17,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -64,7 +64,11 @@ def _declare(lib):
     lib.lsq_xnor_conv2d.restype = i32
     lib.lsq_xnor_conv2d.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp, vp]
     lib.lsq_signw_conv2d.restype = i32
-    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp, vp]
+    lib.lsq_signw_conv2d.argtypes = [vp, f32, vp, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, vp, vp]
+    lib.lsq_signw_weight_bytes.restype = i64
+    lib.lsq_signw_weight_bytes.argtypes = [gp, i32]
+    lib.lsq_signw_prepare_weight.restype = i32
+    lib.lsq_signw_prepare_weight.argtypes = [vp, i32, gp, vp, vp]
     lib.lsq_pool_bias_relu_nhwc.restype = i32
     lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     lib.lsq_pointwise_conv.restype = i32
@@ -281,17 +285,32 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
 
 
+def signw_prepare_weight(wbits: torch.Tensor, planes: int, geom: ConvGeom) -> Optional[torch.Tensor]:
+    """The bf16 operand image of lsq_signw_conv2d's 3x3 fast path for the sign planes ``wbits`` (once per eval
+    session, next to pack_weight); None when the geometry has no fast path."""
+    nbytes = lib().lsq_signw_weight_bytes(ctypes.byref(geom), planes)
+    if nbytes <= 0:
+        return None
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=wbits.device)
+    with _on(wbits):
+        check(lib().lsq_signw_prepare_weight(wbits.data_ptr(), planes, ctypes.byref(geom), out.data_ptr(),
+                                             stream_ptr(wbits.device)), 'lsq_signw_prepare_weight')
+    return out
+
+
 def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: torch.Tensor,
                  bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor, pre: Optional[tuple] = None,
                  relu: bool = False, res_pre: Optional[torch.Tensor] = None,
-                 res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None) -> None:
+                 res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None,
+                 wprep: Optional[torch.Tensor] = None) -> None:
+    """``wprep``: signw_prepare_weight(wbits, ...) of the same weights and geometry (same result, 3x3 fast path)."""
     x = _f32c(x)
     act, slope = _act(relu, prelu, geom.O)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
     nres = (res_pre is not None) + (res_post is not None)
     with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel() * (1 + nres), flops):     # fp32 input read + fp32 output written + residuals read
         check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), None if pre is None else pre[0].data_ptr(),
-                                     None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wscales.shape[0],
+                                     None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), ptr(wprep), wscales.shape[0],
                                      wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope), ptr(res_pre),
                                      ptr(res_post), y.data_ptr(), stream_ptr(x.device)), 'lsq_signw_conv2d')
 

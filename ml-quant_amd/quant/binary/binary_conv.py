@@ -168,9 +168,11 @@ class QuantConv2d(nn.Conv2d):
         if hit is None or hit[0] != stamp:
             scales = wq.plane_scales().to(torch.float32).contiguous()
             wbits, wsum = _hip.pack_weight(self.weight.detach(), geom, scales)
-            hit = (stamp, wbits, wsum, scales)
+            # fp activations: the bf16 operand image of the 3x3 fast path, built once with the planes
+            wprep = _hip.signw_prepare_weight(wbits, scales.shape[0], geom) if self.x_quant == 'fp' else None
+            hit = (stamp, wbits, wsum, scales, wprep)
             self._hip_cache['w'] = hit
-        return hit[1], hit[2], hit[3]
+        return hit[1], hit[2], hit[3], hit[4]
 
     def fused_forward(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
                       res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
@@ -217,12 +219,12 @@ class QuantConv2d(nn.Conv2d):
         kh, kw = self.kernel_size
         geom = _hip.make_geom(n, c, h, w, self.out_channels, kh, kw, self.stride, self.padding,
                               self.dilation, self.groups)
-        wbits, wsum, wscales = self._packed_weights(geom, _hip)
+        wbits, wsum, wscales, wprep = self._packed_weights(geom, _hip)
         ho, wo = _hip.out_hw(geom)
         y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
         bias = None if self.bias is None else self.bias.detach()
         if self.x_quant == 'fp':
-            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y, pre, relu, res_pre, res_post, prelu)
+            _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y, pre, relu, res_pre, res_post, prelu, wprep)
             return y
         xq = self.x_approximate
         k = xq.n_planes

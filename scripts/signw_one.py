@@ -19,9 +19,10 @@ w = torch.randn(o, c, 3, 3, device=dev)
 g = _hip.make_geom(n, c, h, h, o, 3, 3, (stride, stride), (1, 1), (1, 1), 1)
 wsc = w.abs().mean(dim=(1, 2, 3)).view(1, -1).contiguous()
 wbits, _ = _hip.pack_weight(w, g, wsc)
+wprep = None if os.environ.get('LSQ_SIGNW_GENERAL') else _hip.signw_prepare_weight(wbits, 1, g)   # fast path unless asked otherwise
 ho, wo = _hip.out_hw(g)
 y = torch.empty((n, o, ho, wo), device=dev)
 bias = torch.zeros(o, device=dev)
 for _ in range(iters):
-    _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y)
+    _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y, wprep=wprep)
 torch.cuda.synchronize()
