@@ -72,7 +72,6 @@ struct LeanGeo {
   int Hp, Wp, n_otiles, opad64;
   int S;                                         // pixel slots per image: Ho * Wo rounded up to a multiple of 4
   int n_units;                                   // pixel tiles x out-channel tiles
-  int stagger;                                   // start delay of the workgroup in the odd wave slot, in 4096-cycle steps
   FastDiv dS, dWo, dHpWp, dWp, dHW, dGPI, dW, dOt;
 };
 
@@ -124,7 +123,8 @@ __device__ __forceinline__ int paddr(int e, int half) {
 // Pixel slots: every image owns S = Ho * Wo rounded up to 4 consecutive slots, the last S - Ho * Wo of them empty, so
 // that an aligned group of four slots never straddles two images (16-byte epilogue accesses for 7 x 7 images too).
 // ODD: Ho * Wo is not a multiple of 4 (the last group of an image holds fewer than four pixels).
-template <int TN, int ITEMS, bool ODD>
+// NRES: epilogue operands -- 0: none, 1: exactly one of res_pre / res_post on a single weight plane, 2: anything.
+template <int TN, int ITEMS, bool ODD, int NRES>
 __global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsigned char* __restrict__ wexp, LeanGeo geo) {
   constexpr int BM = kLeanBM, TM = 2, BN = 128 * TN;
   constexpr int PL = TN == 2 ? 512 : 832;                  // patch entries the LDS planes hold (2 workgroups per CU)
@@ -351,19 +351,6 @@ __global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsign
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[s][j].v, wf[s][i].v, acc[i][j], 0, 0, 0);
   };
 
-  // epilogue arithmetic: the same operations in the same order as the general kernels (store_tiles)
-  const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
-  auto finish = [&](float d, float prev, float r1, float r2, int i) {
-    float out = (a.accumulate ? prev : ep_bias[i]) + d * ep_scale[i];
-    if (a.final_pass) {
-      out += r1;
-      if (a.relu == LSQ_ACT_RELU) out = fmaxf(out, 0.f);
-      else if (a.relu >= LSQ_ACT_PRELU) out = out > 0.f ? out : ep_slope[i] * out;
-      out += r2;
-    }
-    return out;
-  };
-
 #ifdef LSQ_SIGNW_CLOCKS
   unsigned long long* clk = g_signw_clk ? g_signw_clk + 64ull * blockIdx.x : nullptr;
   int unit_no = 0;
@@ -372,21 +359,23 @@ __global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsign
     clk[1] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // XCC_ID
   }
 #endif
+  auto zero_fill = [&]() {                               // the planes start every unit as zeros: halo entries are never written
+    for (int i = tid; i < 2 * kPlane / 16; i += 256) reinterpret_cast<uint4*>(sP)[i] = make_uint4(0u, 0u, 0u, 0u);
+  };
+
+  // ---- first unit: loads, set-up under their flight, first conversion
   unit_items(unit);
   issue_xloads(0);
   issue_wloads(0);
-  // The two workgroups of a CU start together and, left alone, stay in lockstep through every unit: both stream the
-  // input (HBM reads only), then both store (HBM writes only, the matrix pipe idle).  The one in the odd wave slot of
-  // its SIMD starts half a unit late: one stores and sets up while the other multiplies.
-  if (geo.stagger > 0 && (__builtin_amdgcn_s_getreg((0 << 11) | (0 << 6) | 4) & 1u))
-    for (int i = 0; i < geo.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  zero_fill();
+  unit_tables();
+  __syncthreads();                                       // zero fill and sPre visible
+  convert_store(0);
+  store_w();
   const int ustep = wg8;
   for (;;) {
+    // (here: chunk 0 of the unit is converted and on its way into LDS)
     LSQ_CLK(2);
-    // ---- set-up of the unit, under the flight of its first loads: LDS planes back to zero (the halo entries are never
-    // written), address tables
-    for (int i = tid; i < 2 * kPlane / 16; i += 256) reinterpret_cast<uint4*>(sP)[i] = make_uint4(0u, 0u, 0u, 0u);
-    unit_tables();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -394,15 +383,17 @@ __global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsign
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     const int cur_p0 = p0, cur_o0 = o0;
+    float cur_scale[TM], cur_bias[TM], cur_slope[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { cur_scale[i] = ep_scale[i]; cur_bias[i] = ep_bias[i]; cur_slope[i] = ep_slope[i]; }
     const int next = unit + ustep;
     const bool more = next < unit_end;
-    LSQ_CLK(60);
-    __syncthreads();                                     // zero fill (and, the first time, sPre) visible
-    LSQ_CLK(61);
     for (int cc = 0; cc < cchunks; ++cc) {
       LSQ_CLK(4 + 3 * cc);
-      convert_store(cc);
-      store_w();
+      if (cc > 0) {
+        convert_store(cc);
+        store_w();
+      }
       __syncthreads();                                   // patch and weights of this chunk visible
       LSQ_CLK(5 + 3 * cc);
       if (cc + 1 < cchunks) {                            // the next chunk's loads fly during the MFMAs below
@@ -428,61 +419,132 @@ __global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsign
     }
     LSQ_CLK(3);
 
-    // ---- epilogue: y = act(scale * acc + bias | y + res_pre) + res_post; register group g of a tile = pixel slots
-    // 8 g + 4 (lane >> 5) + 0..3 of the tile, 16 contiguous bytes of one out-channel.  The stores are not waited for.
-    // (two register groups at a time: the next unit's first loads are in flight and hold their registers)
+    // ---- epilogue: y = act(scale * acc + bias | y + res_pre) + res_post, the same operations in the same order as the
+    // general kernels (store_tiles).  Register group g of a tile = pixel slots 8 g + 4 (lane >> 5) + 0..3, 16 contiguous
+    // bytes of one out-channel.  Straight-line code in quarters (pixel tile j, half gh = two register groups x two
+    // out-channel tiles): the residual loads of two quarters are in flight while a third one is computed and stored, the
+    // set-up of the next unit runs in the shadow of the first loads, and no wait ever names a store (vmcnt is in order:
+    // a wait for a load issued after a store would wait for the store).
+    const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
+    auto finish = [&](float d, float prev, float r1, float r2, int i) {
+      float out = (a.accumulate ? prev : cur_bias[i]) + d * cur_scale[i];
+      if (a.final_pass) {
+        out += r1;
+        if (a.relu == LSQ_ACT_RELU) out = fmaxf(out, 0.f);
+        else if (a.relu >= LSQ_ACT_PRELU) out = out > 0.f ? out : cur_slope[i] * out;
+        out += r2;
+      }
+      return out;
+    };
+    constexpr int NQ = 2 * TN;
+    unsigned off[NQ][2][TM];
+    int nval[NQ][2];                                     // real pixels in the group: 4, or fewer at the end of an image
+    bool ook[TM];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      bool ook[TM];
+    for (int i = 0; i < TM; ++i) ook[i] = cur_o0 + i * 32 + col < a.O;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) ook[i] = cur_o0 + i * 32 + col < a.O;
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int gh = 0; gh < 2; ++gh) {
-        unsigned off[2][TM];
-        int nval[2];                                     // real pixels in the group: 4, or fewer at the end of an image
-        f32x4 prev[2][TM], r1[2][TM], r2[2][TM];
+      for (int gl = 0; gl < 2; ++gl) {
+        const int j = q >> 1, g = 2 * (q & 1) + gl;
+        const int p = cur_p0 + (wid * TN + j) * 32 + 8 * g + 4 * kh8;
+        const int n = fdiv(p, geo.dS), r = p - n * S;
+        nval[q][gl] = p < total ? min(max(HoWo - r, 0), 4) : 0;
 #pragma unroll
-        for (int gl = 0; gl < 2; ++gl) {
-          const int g = 2 * gh + gl;
-          const int p = cur_p0 + (wid * TN + j) * 32 + 8 * g + 4 * kh8;
-          const int n = fdiv(p, geo.dS), r = p - n * S;
-          nval[gl] = p < total ? min(max(HoWo - r, 0), 4) : 0;
+        for (int i = 0; i < TM; ++i)
+          off[q][gl][i] = (nval[q][gl] > 0 && ook[i]) ? (unsigned)((n * a.O + cur_o0 + i * 32 + col) * HoWo + r) * 4u : 0u;
+      }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // one quarter: outputs from the accumulators and the (already loaded) operands, 16-byte stores; image ends one by one
+    auto emit = [&](int q, const f32x4 (&pv)[2][TM], const f32x4 (&v1)[2][TM], const f32x4 (&v2)[2][TM]) {
+      const int j = q >> 1;
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int o = cur_o0 + i * 32 + col;
-            const bool full = nval[gl] == 4 && ook[i];
-            off[gl][i] = (nval[gl] > 0 && ook[i]) ? (unsigned)((n * a.O + o) * HoWo + r) * 4u : 0u;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const unsigned lo = full ? off[gl][i] : 0u;  // (partial groups read their operands one by one below)
-            prev[gl][i] = a.accumulate ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.y) + lo) : zero;
-            r1[gl][i] = want_pre ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.res_pre) + lo) : zero;
-            r2[gl][i] = want_post ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.res_post) + lo) : zero;
+      for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int g = 2 * (q & 1) + gl;
+          if (!ODD || nval[q][gl] == 4) {
+            f32x4 out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = finish(acc[i][j][4 * g + k], pv[gl][i][k], v1[gl][i][k], v2[gl][i][k], i);
+#ifdef LSQ_ABL_NOSTORE                                   // (ablation: wrong results) nothing leaves
+            if (out[0] == 12345.678f && out[1] == 1.f) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + off[q][gl][i]) = out;
+#else
+            if (ook[i] && nval[q][gl] == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + off[q][gl][i]) = out;
+#endif
+          } else if (ODD && ook[i]) {                    // end of an image whose size is not a multiple of 4
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              if (k < nval[q][gl]) {
+                const unsigned ok4 = off[q][gl][i] + 4u * k;
+                const float p1 = a.accumulate ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.y) + ok4) : 0.f;
+                const float q1 = want_pre ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res_pre) + ok4) : 0.f;
+                const float q2 = want_post ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res_post) + ok4) : 0.f;
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(a.y) + ok4) = finish(acc[i][j][4 * g + k], p1, q1, q2, i);
+              }
+            }
           }
         }
+    };
+    auto setup_next = [&]() {                            // (unit_items(next) ran before the last chunk's MFMAs)
+#ifdef LSQ_ABL_NOSETUP                                   // (ablation: wrong results) the first unit's tables throughout
+      if (false)
+#endif
+      if (more) {
+        zero_fill();
+        unit_tables();
+      }
+    };
+    if constexpr (NRES == 2) {
+      // general case (several weight planes, or both residuals): quarter by quarter
+      setup_next();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        f32x4 pv[2][TM], v1[2][TM], v2[2][TM];
 #pragma unroll
         for (int gl = 0; gl < 2; ++gl)
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            const int g = 2 * gh + gl;
-            if (!ODD || nval[gl] == 4) {
-              f32x4 out;
-#pragma unroll
-              for (int k = 0; k < 4; ++k) out[k] = finish(acc[i][j][4 * g + k], prev[gl][i][k], r1[gl][i][k], r2[gl][i][k], i);
-              if (ook[i] && nval[gl] == 4) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.y) + off[gl][i]) = out;
-            } else if (ODD && ook[i]) {                  // end of an image whose size is not a multiple of 4
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                if (k < nval[gl]) {
-                  const unsigned ok4 = off[gl][i] + 4u * k;
-                  const float pv = a.accumulate ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.y) + ok4) : 0.f;
-                  const float q1 = want_pre ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res_pre) + ok4) : 0.f;
-                  const float q2 = want_post ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.res_post) + ok4) : 0.f;
-                  *reinterpret_cast<float*>(reinterpret_cast<char*>(a.y) + ok4) = finish(acc[i][j][4 * g + k], pv, q1, q2, i);
-                }
-              }
-            }
+            const unsigned lo = (nval[q][gl] == 4 && ook[i]) ? off[q][gl][i] : 0u;     // (partial groups read one by one)
+            pv[gl][i] = a.accumulate ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.y) + lo) : zero4;
+            v1[gl][i] = want_pre ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.res_pre) + lo) : zero4;
+            v2[gl][i] = want_post ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.res_post) + lo) : zero4;
           }
+        emit(q, pv, v1, v2);
       }
+    } else if constexpr (NRES == 1) {
+      // exactly one residual operand, one weight plane
+      const char* rs = reinterpret_cast<const char*>(want_pre ? a.res_pre : a.res_post);
+      f32x4 ring[2][2][TM];
+      auto fetch = [&](int q) {
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            ring[q & 1][gl][i] = *reinterpret_cast<const f32x4*>(rs + ((nval[q][gl] == 4 && ook[i]) ? off[q][gl][i] : 0u));
+      };
+      fetch(0);
+      fetch(1);
+      setup_next();
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        f32x4 pv[2][TM], v1[2][TM], v2[2][TM];
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            pv[gl][i] = zero4;
+            v1[gl][i] = want_pre ? ring[q & 1][gl][i] : zero4;
+            v2[gl][i] = want_pre ? zero4 : ring[q & 1][gl][i];
+          }
+        emit(q, pv, v1, v2);
+        if (q + 2 < NQ) fetch(q + 2);
+      }
+    } else {
+      setup_next();
+      const f32x4 none[2][TM] = {{zero4, zero4}, {zero4, zero4}};
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) emit(q, none, none, none);
     }
     LSQ_CLK(63);
 #ifdef LSQ_SIGNW_CLOCKS
@@ -490,18 +552,28 @@ __global__ __launch_bounds__(256, 2) void signw_conv_lean(SwArgs a, const unsign
 #endif
     if (!more) break;
     unit = next;
+    __syncthreads();                                     // zero fill visible
+    convert_store(0);
+    store_w();
   }
 }
 
+template <int TN, int ITEMS, bool ODD>
+void launch_nres(int nres, dim3 grid, hipStream_t st, const SwArgs& a, const unsigned char* w, const LeanGeo& geo) {
+  if (nres == 0) hipLaunchKernelGGL((signw_conv_lean<TN, ITEMS, ODD, 0>), grid, dim3(256), 0, st, a, w, geo);
+  else if (nres == 1) hipLaunchKernelGGL((signw_conv_lean<TN, ITEMS, ODD, 1>), grid, dim3(256), 0, st, a, w, geo);
+  else hipLaunchKernelGGL((signw_conv_lean<TN, ITEMS, ODD, 2>), grid, dim3(256), 0, st, a, w, geo);
+}
+
 template <int TN>
-int launch_items(int items, bool odd, dim3 grid, hipStream_t st, const SwArgs& a, const unsigned char* w, const LeanGeo& geo) {
+int launch_items(int items, bool odd, int nres, dim3 grid, hipStream_t st, const SwArgs& a, const unsigned char* w, const LeanGeo& geo) {
   // (instantiated: the combinations that stay inside 256 registers without spilling)
   if (items == 1) {
-    if (odd) hipLaunchKernelGGL((signw_conv_lean<TN, 1, true>), grid, dim3(256), 0, st, a, w, geo);
-    else hipLaunchKernelGGL((signw_conv_lean<TN, 1, false>), grid, dim3(256), 0, st, a, w, geo);
+    if (odd) launch_nres<TN, 1, true>(nres, grid, st, a, w, geo);
+    else launch_nres<TN, 1, false>(nres, grid, st, a, w, geo);
   } else if (items == 2 && TN == 1) {
-    if (odd) hipLaunchKernelGGL((signw_conv_lean<1, 2, true>), grid, dim3(256), 0, st, a, w, geo);
-    else hipLaunchKernelGGL((signw_conv_lean<1, 2, false>), grid, dim3(256), 0, st, a, w, geo);
+    if (odd) launch_nres<1, 2, true>(nres, grid, st, a, w, geo);
+    else launch_nres<1, 2, false>(nres, grid, st, a, w, geo);
   } else {
     return LSQ_E_UNSUPPORTED;
   }
@@ -621,19 +693,15 @@ int lean_launch(const SwArgs& a, const void* wprep, int plane, const lsq_conv_ge
   geo.dS = make_fastdiv(S); geo.dWo = make_fastdiv(a.Wo); geo.dHpWp = make_fastdiv((long long)Hp * Wp);
   geo.dWp = make_fastdiv(Wp); geo.dHW = make_fastdiv((long long)g->H * g->W);
   geo.dGPI = make_fastdiv(((long long)g->H * g->W + 3) / 4); geo.dW = make_fastdiv(g->W); geo.dOt = make_fastdiv(n_otiles);
-  // half a unit (chunks x ~6500 cycles + set-up and epilogue), when a workgroup has at least three units to walk
-  const long long per_wg = units / 512;
-  geo.stagger = per_wg >= 3 ? (int)(((long long)(g->C / kPC) * 6500 + 24000) / 2 / 4096) : 0;
-#ifdef LSQ_SIGNW_STAGGER
-  geo.stagger = per_wg >= 3 ? LSQ_SIGNW_STAGGER : 0;
-#endif
   const unsigned char* w = (const unsigned char*)wprep + (long long)plane * (g->C / kPC) * kTaps * opad64 * kPRow;
   // persistent workgroups: two per CU (256 CUs), a multiple of 8 (one share per XCD)
   long long wgs = (units + 7) / 8 * 8;
   if (wgs > 512) wgs = 512;
   const dim3 grid((unsigned)wgs);
   const bool odd = (a.Ho * a.Wo) % 4 != 0;
-  return wide ? launch_items<2>(items, odd, grid, st, a, w, geo) : launch_items<1>(items, odd, grid, st, a, w, geo);
+  const bool want_pre = a.final_pass && a.res_pre, want_post = a.final_pass && a.res_post;
+  const int nres = (a.accumulate || (want_pre && want_post)) ? 2 : (want_pre || want_post) ? 1 : 0;
+  return wide ? launch_items<2>(items, odd, nres, grid, st, a, w, geo) : launch_items<1>(items, odd, nres, grid, st, a, w, geo);
 }
 
 }  // namespace signw
