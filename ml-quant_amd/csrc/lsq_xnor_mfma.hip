@@ -90,15 +90,27 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       px.n += 1;
     }
   };
+  // The three words a pixel's kernel row touches (kw = 0, 1, 2) are 24 contiguous bytes of the plane; the lane of
+  // half hh = 0 takes the first 12 (word 0 low, word 0 high, word 1 low), the lane of half 1 the last 12 (word 1 high,
+  // word 2 low, word 2 high): ONE 12-byte load per (kernel row, plane) instead of three 4-byte ones -- a vector-memory
+  // instruction costs a 16-cycle address pass whatever its width, and with dword loads that pass, not the matrix
+  // core, paced the layers (round 3: 1.20 -> 1.06 ms per forward).  The MFMA sums over k in any order, so dword d of
+  // a lane simply IS k-step (row, d); the weight fragments are laid out to match (see the expansion below).
+  typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
   auto request = [&](const Pix& px, int j, unsigned (&x)[NW]) {
-    // dword index of (word, half) = 2 * word + hh; words: [plane][n][GG][Hp][Wp]; lanes past the last pixel (last tile
+    // dword index of (word, half) = 2 * word + half; words: [plane][n][GG][Hp][Wp]; lanes past the last pixel (last tile
     // only) read the words of image 0 and store nothing
     const int n = px.n < a.N ? px.n : 0;
-    const unsigned base = 2u * (unsigned)(((n * GG + j) * a.Hp + px.ho * a.sh) * a.Wp + px.wo * a.sw) + (unsigned)hh;
+    const unsigned base = 2u * (unsigned)(((n * GG + j) * a.Hp + px.ho * a.sh) * a.Wp + px.wo * a.sw) + 3u * (unsigned)hh;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int p = 0; p < KX; ++p) x[t * KX + p] = xd[base + 2u * (unsigned)a.tap_xoff[t] + (unsigned)p * plane_stride];
+      for (int p = 0; p < KX; ++p) {
+        const u32x3 v = *reinterpret_cast<const u32x3*>(xd + base + 2u * (unsigned)a.tap_xoff[3 * kh] + (unsigned)p * plane_stride);
+        x[(3 * kh + 0) * KX + p] = v.x;
+        x[(3 * kh + 1) * KX + p] = v.y;
+        x[(3 * kh + 2) * KX + p] = v.z;
+      }
   };
 
   // wave-major numbering: when the tiles do not divide evenly, the waves with one tile more sit in different
@@ -123,8 +135,13 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   for (int e = tid; e < TAPS * GG * 64; e += NT) {
     const int L = e & 63, tj = e >> 6;
     const int fj = tj / TAPS, ft = tj - fj * TAPS;                                               // fragment order: word-major
-    const unsigned long long w = a.wbits[(long long)(ft * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
-    const unsigned d = (L >> 5) ? (unsigned)(w >> 32) : (unsigned)w;
+    // step ft = (kernel row, dword dd of the lane's 12 bytes): half 0 holds (kw 0 low, kw 0 high, kw 1 low), half 1
+    // (kw 1 high, kw 2 low, kw 2 high)
+    const int fkh = ft / 3, dd = ft - 3 * fkh, lh = L >> 5;
+    const int pos = 3 * lh + dd;                                                                  // 0..5: dword of the 24 bytes
+    const int tap = 3 * fkh + (pos >> 1);
+    const unsigned long long w = a.wbits[(long long)(tap * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
+    const unsigned d = (pos & 1) ? (unsigned)(w >> 32) : (unsigned)w;
     v4i out[2];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -348,7 +365,7 @@ int launch_gg(const ConvArgs& a, hipStream_t st) {
 
 int xnor_conv_mfma(const ConvArgs& a, int kx, int groups, hipStream_t st) {
   const long long total = (long long)a.N * a.Ho * a.Wo;
-  if (groups != 1 || a.KH != 3 || a.KW != 3 || a.O % 32 || total * a.O >= (1ll << 30) || a.xplane_words * kx >= (1ll << 30))
+  if (groups != 1 || a.KH != 3 || a.KW != 3 || a.dw != 1 || a.O % 32 || total * a.O >= (1ll << 30) || a.xplane_words * kx >= (1ll << 30))
     return kXnorMfmaNotEligible;
   return kx == 2 ? launch_gg<2>(a, st) : launch_gg<1>(a, st);
 }
