@@ -372,6 +372,39 @@ def f8_checkpoints():
     save('f8_checkpoints', **out)
 
 
+# ----------------------------------------------------------------------------- F9 train-mode step
+TRAIN_PAIRS = [('ls-2', 'ls-1'), ('ls-1', 'ls-1'), ('gf-2', 'ls-1'), ('ls-T', 'ls-1'), ('fp', 'ls-1'), ('ls-1', 'gf-2'),
+               ('ls-1', 'ls-2'), ('fp', 'fp')]
+
+
+def f9_train():
+    """One train-mode forward + backward of the reference's QuantConv2d (ste.py:51-66, weight_quantization.py:29-31,
+    :97-105): output, gradients of input / weight / bias for a fixed upstream gradient, the weight-scale buffers the
+    forward cached, and the eval-mode output that then reuses them."""
+    out = {}
+    x0 = detgen.normal('f9.x', (3, 32, 10, 10), scale=1.1)
+    gy = detgen.normal('f9.gy', (3, 24, 10, 10))
+    clamp = {'kind': 'symmetric', 'alpha': 2}
+    for xs, ws in TRAIN_PAIRS:
+        conv = RefQuantConv2d(xs, ws, 32, 24, 3, clamp, padding=1, bias=True)
+        with torch.no_grad():
+            conv.weight.copy_(detgen.normal('f9.w', conv.weight.shape, scale=0.3))
+            conv.bias.copy_(detgen.normal('f9.b', conv.bias.shape, scale=0.1))
+        conv.train()
+        x = x0.clone().requires_grad_()
+        y = conv(x)
+        y.backward(gy)
+        key = f'{xs}_{ws}'
+        out[key + '_y'], out[key + '_gx'] = y, x.grad
+        out[key + '_gw'], out[key + '_gb'] = conv.weight.grad, conv.bias.grad
+        for name, buf in conv.w_approximate.named_buffers():
+            out[key + '_w_' + name] = buf
+        conv.eval()
+        with torch.no_grad():
+            out[key + '_y_eval'] = conv(x0)
+    save('f9_train', **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     if only:
@@ -385,3 +418,4 @@ if __name__ == '__main__':
     f5_conv()
     f6_models()
     f7_lenet()
+    f9_train()

@@ -1,0 +1,250 @@
+"""Round-3 GPU tests: the sign-weight fast path against the general kernels (bit for bit), the train-mode step on the
+device against the reference's fixture, and the full-size checks of what bench.py runs (whole networks at batch 256,
+the fp-activation layers at batch 256 against fp64)."""
+
+import numpy as np
+import pytest
+import torch
+
+import detgen
+from oracle import lsq_exact as E
+from oracle import ref_port as P
+from test_train_step import TRAIN_PAIRS, make_train_conv, rel, train_step
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+TOL = 1e-4
+
+
+def _hip():
+    from quant import _hip
+    return _hip
+
+
+def rel_err(y, ref):
+    return float((y - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+# ---------------------------------------------------------------------------------------------- sign-weight fast path
+FAST_CASES = [
+    # (N, C, H, W, O, stride, pad, dil, planes, what)
+    (3, 64, 56, 56, 64, 1, 1, 1, 1, 'layer1: tiles cross rows and images'),
+    (5, 512, 7, 7, 512, 1, 1, 1, 1, '7x7: pixel slots, groups of 4 that end an image'),
+    (9, 16, 7, 7, 40, 1, 1, 1, 1, 'one channel chunk, 40 out-channels (ragged tile)'),
+    (4, 32, 5, 9, 72, 1, 1, 1, 2, 'odd image size (45 pixels), two weight planes (accumulate path)'),
+    (6, 128, 28, 28, 256, 2, 1, 1, 1, 'stride 2: 128-slot tiles, two conversion items'),
+    (3, 64, 56, 56, 128, 2, 1, 1, 1, 'first down-sampling layer'),
+    (2, 48, 20, 20, 64, (2, 1), 1, 1, 1, 'anisotropic stride'),
+    (2, 32, 18, 18, 64, 1, 2, 2, 1, 'dilation 2 (tap offsets)'),
+    (70, 64, 14, 14, 64, 1, 1, 1, 1, 'more units than one round of workgroups per XCD'),
+    (1, 16, 2, 2, 16, 1, 1, 1, 1, 'smallest image the fast path takes (4 pixels)'),
+    (2, 32, 12, 12, 32, 1, 0, 1, 1, 'no padding'),
+]
+
+
+@pytest.mark.parametrize('n,c,h,w,o,stride,pad,dil,planes,what', FAST_CASES)
+def test_signw_fast_path_equals_general_kernels(n, c, h, w, o, stride, pad, dil, planes, what):
+    """lsq_signw_conv2d with the prepared weights (3x3 fast path: 16-byte loads, persistent workgroups) against the same
+    call without them (general kernels): same arithmetic in the same order, so the outputs are equal bit for bit --
+    plain, and with every epilogue variant (folded batch norm, ReLU / PReLU, one or both residuals, no bias, no clamp)."""
+    hip = _hip()
+    st = stride if isinstance(stride, tuple) else (stride, stride)
+    x = (detgen.normal(f'r3.fast.x{n}.{c}.{h}', (n, c, h, w), scale=1.3)).to(DEV)
+    wt = detgen.normal(f'r3.fast.w{o}.{c}', (o, c, 3, 3)).to(DEV)
+    g = hip.make_geom(n, c, h, w, o, 3, 3, st, (pad, pad), (dil, dil), 1)
+    if planes == 1:
+        wsc = wt.abs().mean(dim=(1, 2, 3)).view(1, -1).contiguous()
+    else:
+        wsc = torch.stack(P.weight_scales(wt.cpu(), 'gf-2')).to(DEV).contiguous()
+    wbits, _ = hip.pack_weight(wt, g, wsc)
+    wprep = hip.signw_prepare_weight(wbits, planes, g)
+    assert wprep is not None, what
+    ho, wo = hip.out_hw(g)
+    shape = (n, o, ho, wo)
+    bias = detgen.normal('r3.fast.b', (o,), scale=0.2).to(DEV)
+    pre = (detgen.uniform('r3.fast.ps', (c,), 0.5, 1.5).to(DEV), detgen.normal('r3.fast.pt', (c,), scale=0.2).to(DEV))
+    r1 = detgen.normal('r3.fast.r1', shape).to(DEV)
+    r2 = detgen.normal('r3.fast.r2', shape).to(DEV)
+    slope1 = torch.full((1,), 0.25, device=DEV)
+    slope_c = detgen.uniform('r3.fast.sl', (o,), 0.1, 0.4).to(DEV)
+    variants = [
+        dict(alpha=2.0, bias=bias),
+        dict(alpha=2.0, bias=bias, pre=pre, prelu=slope1, res_post=r2),          # the XNOR block half of the reference's fp yaml
+        dict(alpha=3.0, bias=bias, pre=pre, relu=True, res_pre=r1),
+        dict(alpha=-1.0, bias=None, prelu=slope_c, res_pre=r1, res_post=r2),     # clamp_identity, no bias, both residuals
+    ]
+    for kw in variants:
+        alpha, b = kw.pop('alpha'), kw.pop('bias')
+        y_fast = torch.full(shape, float('nan'), device=DEV)
+        y_gen = torch.full(shape, float('nan'), device=DEV)
+        hip.signw_conv2d(x, alpha, wbits, wsc, b, g, y_fast, wprep=wprep, **kw)
+        hip.signw_conv2d(x, alpha, wbits, wsc, b, g, y_gen, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(y_fast, y_gen), (what, sorted(kw), rel_err(y_fast, y_gen))
+    # and against fp64 on the device (plain variant): inside the 1e-4 bar
+    xq = x.clamp(-2, 2).double()
+    wq = sum(wsc[q].view(-1, 1, 1, 1).double() * s.double()
+             for q, s in enumerate(_sign_planes(wt, wsc)))
+    ref = torch.nn.functional.conv2d(xq, wq, bias.double(), st, pad, dil).float()
+    y = torch.empty(shape, device=DEV)
+    hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y, wprep=wprep)
+    assert rel_err(y, ref) <= TOL, (what, rel_err(y, ref))
+
+
+def _sign_planes(w, scales):
+    """plane q = sign(w - sum_{r<q} u_r plane_r) (weight_quantization.py eval branch)."""
+    out, res = [], torch.zeros_like(w)
+    for q in range(scales.shape[0]):
+        s = P.pm1(w - res)
+        out.append(s)
+        res = res + scales[q].view(-1, 1, 1, 1) * s
+    return out
+
+
+def test_signw_prepare_weight_declines_other_geometries():
+    hip = _hip()
+    wbits = torch.zeros(64, dtype=torch.int64, device=DEV)
+    for kw in (dict(kh=5, kw_=5), dict(groups=2), dict(c=20), dict(kh=1, kw_=1)):
+        c, kh, kw_, groups = kw.get('c', 32), kw.get('kh', 3), kw.get('kw_', 3), kw.get('groups', 1)
+        g = hip.make_geom(2, c, 8, 8, 32, kh, kw_, (1, 1), (1, 1), (1, 1), groups)
+        assert hip.lib().lsq_signw_weight_bytes(g, 1) == 0
+        assert hip.signw_prepare_weight(wbits, 1, g) is None
+
+
+# ---------------------------------------------------------------------------------------------- train-mode step on the device
+@pytest.mark.parametrize('xs,ws', TRAIN_PAIRS)
+def test_train_step_on_device_vs_reference(golden, xs, ws):
+    """SURVEY 8(f) rank 3 with numbers: the train-mode QuantConv2d step on cuda:0 (torch formulation on the device, the
+    HIP solver underneath for ls-2 / ls-T) against the REFERENCE's own step (f9_train.npz): output, input / weight /
+    bias gradients, cached weight scales; then eval() on the device takes the HIP kernels with the scales the
+    train-mode forward cached (GF-k and LS-2 weight quantizers included) and lands on the reference's eval output.
+    Bounds: the device convolution and reductions associate differently from the CPU's (1e-5); the activation solve
+    is exact on the device and fp32 in the reference, which on these rows picks the same candidate."""
+    g = golden('f9_train')
+    key = f'{xs}_{ws}'
+    conv = make_train_conv(xs, ws, DEV)
+    x, y = train_step(conv, DEV)
+    for name, buf in conv.w_approximate.named_buffers():
+        assert torch.allclose(buf.cpu(), g[key + '_w_' + name], rtol=2e-6, atol=0), name
+    assert rel(y, g[key + '_y']) <= 1e-5, rel(y, g[key + '_y'])
+    assert rel(x.grad, g[key + '_gx']) <= 1e-5
+    assert rel(conv.weight.grad, g[key + '_gw']) <= 1e-5
+    assert rel(conv.bias.grad, g[key + '_gb']) <= 1e-5
+    conv.eval()
+    with torch.no_grad():
+        ye = conv(x.detach())
+    assert rel(ye, g[key + '_y_eval']) <= TOL, rel(ye, g[key + '_y_eval'])
+    if ws != 'fp':
+        assert 'w' in conv._hip_cache                                       # eval ran on the HIP path
+
+
+def test_fp_fp_on_device_is_plain_conv2d():
+    conv = make_train_conv('fp', 'fp', DEV, clamp=None)
+    plain = torch.nn.Conv2d(32, 24, 3, padding=1, bias=True).to(DEV)
+    plain.load_state_dict({'weight': conv.weight.detach(), 'bias': conv.bias.detach()})
+    x, y = train_step(conv, DEV)
+    x2, y2 = train_step(plain, DEV)
+    assert torch.equal(y, y2) and torch.equal(x.grad, x2.grad) and torch.equal(conv.weight.grad, plain.weight.grad)
+
+
+# ---------------------------------------------------------------------------------------------- full size: what bench.py runs
+def _bench_model(act):
+    import bench
+    arch = bench.imagenet_arch('ls-2', 3) if act == 'ls-2' else bench.imagenet_arch('fp', 2)
+    return bench.build_model(arch, DEV)
+
+
+@pytest.mark.parametrize('act', ['ls-2', 'fp'])
+def test_full_size_whole_network(act):
+    """The benchmark's own workload -- ResNet-18 ImageNet, ls-1 weights, ls-2 (or fp) activations, batch 256 of
+    3 x 224 x 224 (intent of the reference's tests/models/test_resnet.py:112-136 at BASELINE size): deterministic,
+    per-sample independent (rows 40:48 alone == rows 40:48 of the batch, bit for bit), and every one of the 16
+    quantized layers checked in place on three rows of the batch (module-by-module path, forward hooks): the solved v1
+    equals the exact oracle on the very tensor the layer quantized, and the layer's output is within 1e-4 of an fp64
+    convolution of its own quantized input."""
+    import quant.models.resnet as R
+    from quant.binary.binary_conv import QuantConv2d
+    model = _bench_model(act)
+    x = torch.randn(256, 3, 224, 224, generator=torch.Generator().manual_seed(0)).to(DEV)
+    rows = [0, 131, 255]
+    seen = []
+
+    def hook(mod, args, out):
+        scales = None if act == 'fp' else mod.last_act_scales.clone()
+        seen.append((mod, args[0].clone(), out.clone(), scales))
+    with torch.no_grad():
+        def features(inp):                                                  # everything up to the fp classifier
+            for stage in model.blocks:
+                inp = stage(inp)
+            return inp
+        f1 = features(x).clone()
+        y1 = model(x).clone()
+        assert torch.equal(f1, features(x)) and torch.equal(y1, model(x))   # deterministic
+        # per-sample independence: bit for bit through the 16 quantized layers (the average pool and the Linear of the
+        # classifier are library kernels whose summation order depends on the batch size)
+        assert torch.equal(features(x[40:48].contiguous()), f1[40:48])
+        assert torch.allclose(model(x[40:48].contiguous()), y1[40:48], rtol=1e-5, atol=1e-5)
+        assert bool(torch.isfinite(y1).all())
+        handles = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, QuantConv2d)]
+        R.FUSE_BLOCKS = False
+        try:
+            ym = model(x[rows].contiguous())
+        finally:
+            R.FUSE_BLOCKS = True
+            for hd in handles:
+                hd.remove()
+        assert len(seen) == 16
+        for li, (conv, xin, yout, scales) in enumerate(seen):
+            alpha = conv._alpha()
+            xc = xin.clamp(-alpha, alpha)
+            if act == 'ls-2':
+                want = E.solve_rows(xc.reshape(len(rows), -1).cpu().numpy(), False, 3)
+                assert np.array_equal(scales[0].cpu().numpy(), want), (li, scales[0], want)
+                xq = P.quant_ls2(xc, scales[0], scales[1])[2]
+            else:
+                xq = xc
+            wq = conv.w_approximate.v1.view(-1, 1, 1, 1) * P.pm1(conv.weight)
+            ref = torch.nn.functional.conv2d(xq.double(), wq.double(), conv.bias.double(), conv.stride, 1).float()
+            assert rel_err(yout, ref) <= TOL, (li, rel_err(yout, ref))
+        # fused blocks (the batch run) and the module-by-module path agree on the same rows
+        cos = torch.nn.functional.cosine_similarity(ym.flatten(), y1[rows].flatten(), dim=0)
+        assert 1.0 - float(cos) <= 1e-3
+
+
+@pytest.mark.parametrize('c, h, o, stride', [(64, 56, 64, 1), (64, 56, 128, 2), (128, 28, 128, 1), (128, 28, 256, 2),
+                                             (256, 14, 256, 1), (256, 14, 512, 2), (512, 7, 512, 1)])
+def test_full_size_fp_activation_layers(c, h, o, stride):
+    """The seven QuantConv2d shapes of ResNet-18 with x_quant = 'fp' at batch 256 (BASELINE config 3, the fast path as
+    bench.py --act fp runs it, folded batch norm + PReLU + residual included) against an fp64 convolution: <= 1e-4."""
+    from quant.binary.binary_conv import QuantConv2d
+    torch.manual_seed(c + h + 1)
+    n = 256
+    x = torch.randn(n, c, h, h, device=DEV) * 1.4
+    conv = QuantConv2d('fp', 'ls-1', c, o, 3, {'kind': 'symmetric', 'alpha': 2}, stride=stride, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm2d(c).to(DEV)
+    prelu = torch.nn.PReLU().to(DEV)
+    with torch.no_grad():
+        conv.w_approximate.v1.copy_(conv.weight.abs().mean(dim=(1, 2, 3)))
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    conv.eval()
+    bn.eval()
+    ho = (h - 1) // stride + 1
+    res = torch.randn(n, o, ho, ho, device=DEV)
+    with torch.no_grad():
+        y1 = conv.fused_forward(x, bn, res_post=res, prelu=prelu.weight).clone()
+        y2 = conv.fused_forward(x, bn, res_post=res, prelu=prelu.weight)
+        assert torch.equal(y1, y2)
+        assert torch.equal(conv.fused_forward(x[100:103].contiguous(), bn, res_post=res[100:103].contiguous(), prelu=prelu.weight),
+                           y1[100:103])
+        wq = (conv.w_approximate.v1.view(-1, 1, 1, 1) * P.pm1(conv.weight)).double()
+        ref = torch.empty_like(y1)
+        for i in range(0, n, 32):
+            xq = bn(x[i:i + 32]).clamp(-2, 2).double()
+            z = torch.nn.functional.conv2d(xq, wq, conv.bias.double(), stride, 1)
+            z = torch.where(z > 0, z, prelu.weight.double() * z) + res[i:i + 32].double()
+            ref[i:i + 32] = z.float()
+    assert rel_err(y1, ref) <= TOL, rel_err(y1, ref)
