@@ -197,9 +197,12 @@ int lsq_pool_bias_relu_nhwc(const float* x_nhwc, int N, int C, int H, int W, int
  * <= 2^-24 relative per product: fp32 rounding level, any finite operand); 2: two bf16 terms (three passes, ~2^-17
  * per product); 22: fp16 leading term + fp16 remainder scaled by 2^11 (three passes, 2^-23 per product; operands
  * must be below 65504 in magnitude -- beyond that the leading term is inf and so is the output).
+ *   overflow   NULL, or an int32 on the device the caller has zeroed: split 22 sets it to 1 when an element of x or
+ *              w is at or beyond 65504 (or NaN), i.e. outside that split's domain -- the caller then knows the output
+ *              is not to be used and can repeat the call with split 3.
  */
 int lsq_stem_conv_pool(const float* x, int N, int H, int W, const float* w, const float* bias, int split,
-                       float* y, void* stream);
+                       float* y, int32_t* overflow, void* stream);
 
 /*
  * Strided 1x1 convolution: y[n][o][ho][wo] = sum_c w[o][c] * x[n][c][ho*stride][wo*stride] + bias[o], the projection

@@ -59,6 +59,7 @@ union Frag {
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 constexpr float kLoScale = 2048.f;
+constexpr float kHalfMax = 65504.f;        // largest fp16: operands at or beyond it (or NaN) are outside the fp16 split's domain
 
 template <int SPLIT, bool HALF>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&t)[SPLIT]) {
@@ -92,6 +93,7 @@ struct StemArgs {
   const float* bias;   // [64]
   float* y;            // [N][64][Hp][Wp]
   int N, H, W, Hc, Wc, Hp, Wp;
+  int* overflow;       // fp16 split only: set to 1 when an operand is outside the split's domain (may be null)
 };
 
 template <int SPLIT>
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
   const int q0 = wid & 1;                 // first conv row of this wave
   const int xl_ = lane & 31, g = lane >> 5;
   const float ninf = -__builtin_inff();
+  bool bad = false;                       // fp16 split: an operand at or beyond 65504 (or NaN) was seen
 
   // ---- A fragments (weights) of this wave's 32 out-channels, all 11 k-steps, hi and lo
   Frag af[SPLIT][kSteps];
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned t[SPLIT];
+        if constexpr (HALF) bad = bad || !(fmaxf(fabsf(v[2 * j]), fabsf(v[2 * j + 1])) < kHalfMax);
         split_pair<SPLIT, HALF>(v[2 * j], v[2 * j + 1], t);
 #pragma unroll
         for (int i = 0; i < SPLIT; ++i) af[i][s].u[j] = t[i];
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
     for (int it = h0; it < h0 + kHalf; ++it) {
       if (it < kIt && tid + 256 * it < kPairs) {
         unsigned sp[SPLIT];
+        if constexpr (HALF) bad = bad || !(fmaxf(fabsf(t[it - h0].x), fabsf(t[it - h0].y)) < kHalfMax);
         split_pair<SPLIT, HALF>(t[it - h0].x, t[it - h0].y, sp);
 #pragma unroll
         for (int i = 0; i < SPLIT; ++i) lds.xs[i][tid + 256 * it] = sp[i];
@@ -311,6 +316,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       }
     }
   }
+  if constexpr (HALF) {
+    if (a.overflow && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.overflow, 1);
+  }
 }
 
 }  // namespace
@@ -319,12 +327,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 using namespace lsq;
 
 extern "C" int lsq_stem_conv_pool(const float* x, int N, int H, int W, const float* w, const float* bias, int split,
-                                  float* y, void* stream) {
+                                  float* y, int32_t* overflow, void* stream) {
   if (!x || !w || !bias || !y) return LSQ_E_NULL;
   if (N <= 0 || H < 8 || W < 8 || (W & 1) || ((uintptr_t)x % 8)) return LSQ_E_SHAPE;
   if (split != 2 && split != 3 && split != 22) return LSQ_E_SCHEME;
   StemArgs a = {};
-  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.overflow = overflow;
   a.N = N; a.H = H; a.W = W;
   a.Hc = (H + 6 - 7) / 2 + 1;
   a.Wc = (W + 6 - 7) / 2 + 1;

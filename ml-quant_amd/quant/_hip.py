@@ -74,7 +74,7 @@ def _declare(lib):
     lib.lsq_pointwise_conv.restype = i32
     lib.lsq_pointwise_conv.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.lsq_stem_conv_pool.restype = i32
-    lib.lsq_stem_conv_pool.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp]
+    lib.lsq_stem_conv_pool.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]
 
 
 def lib():
@@ -331,24 +331,68 @@ def pool_bias_relu_nhwc(x: torch.Tensor, kernel: int, stride: int, pad: int, bia
     return y
 
 
+_stem_guard = {}
+
+
+def _stem_guard_state(device):
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _stem_guard.get(idx)
+    if st is None:
+        st = _stem_guard[idx] = {'flag': torch.zeros((1,), dtype=torch.int32, device=torch.device('cuda', idx)),
+                                 'host': torch.zeros((1,), dtype=torch.int32).pin_memory(), 'event': None, 'tripped': False}
+    return st
+
+
+def stem_overflow_tripped(device) -> bool:
+    """True once a FINISHED stem_conv_pool(split=22) call on ``device`` has reported an operand outside the fp16 split's
+    domain (|value| >= 65504 or NaN).  Never blocks: the kernel raises a device flag, its copy to pinned host memory
+    rides on the launch stream and is looked at only when its event has completed -- so the report arrives a call or
+    two after the offending one (whose output holds inf / nan).  Callers switch to split 3 (any finite input) then."""
+    st = _stem_guard_state(device)
+    ev = st['event']
+    if ev is not None and ev.query():
+        st['event'] = None
+        if int(st['host'][0]) != 0:
+            st['tripped'] = True
+    return st['tripped']
+
+
+def stem_overflow_reset(device) -> None:
+    """Forget an earlier report (after the caller has dealt with it); waits for the device."""
+    torch.cuda.synchronize(device)
+    st = _stem_guard_state(device)
+    st['event'], st['tripped'] = None, False
+    st['flag'].zero_()
+    st['host'].zero_()
+
+
 def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: int = 3) -> torch.Tensor:
     """``max_pool2d(relu(conv2d(x, w, stride=2, padding=3) + bias), 3, 2, 1)`` for a 7x7 convolution 3 -> 64
     channels (batch norm already folded into ``w`` / ``bias``) as ONE kernel, NCHW fp32 in and out.  ``split``: how the
     fp32 operands are fed to the 16-bit matrix cores -- 3: three bf16 terms, six MFMA passes, fp32-class accuracy, any
     finite input; 2: two bf16 terms, three passes, ~2^-17 per product; 22: fp16 leading term + scaled fp16 remainder,
     three passes, fp32-class accuracy (2^-23 per product), operands below 65504 in magnitude (larger ones become
-    inf / nan in the output: normalised images are far inside)."""
+    inf / nan in the output, and the call reports them: ``stem_overflow_tripped``)."""
     x, w, bias = _f32c(x), _f32c(w), _f32c(bias)
     n, c, h, wd = x.shape
-    if c != 3 or tuple(w.shape) != (64, 3, 7, 7) or wd % 2:
-        raise LsqHipError('stem_conv_pool: 7x7 stride-2 convolution from 3 to 64 channels, even width')
+    if c != 3 or tuple(w.shape) != (64, 3, 7, 7) or wd % 2 or h < 8 or wd < 8 or x.data_ptr() % 8:
+        raise LsqHipError('stem_conv_pool: 7x7 stride-2 convolution from 3 to 64 channels, even width, at least 8 x 8, 8-byte aligned')
     hc, wc = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
     hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
     y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device)
     flops = 2 * (6 if split == 3 else 3) * n * 64 * hc * wc * 147      # 16-bit MFMA passes issued
+    guard = _stem_guard_state(x.device) if split == 22 else None
+    if guard is not None:
+        stem_overflow_tripped(x.device)                                   # (collect a finished report before the flag is reused)
     with _on(x), _Timed('lsq_stem_conv_pool', 4 * x.numel() + 4 * y.numel(), flops):
         check(lib().lsq_stem_conv_pool(x.data_ptr(), n, h, wd, w.data_ptr(), bias.data_ptr(), int(split), y.data_ptr(),
-                                       stream_ptr(x.device)), 'lsq_stem_conv_pool')
+                                       None if guard is None else guard['flag'].data_ptr(), stream_ptr(x.device)),
+              'lsq_stem_conv_pool')
+        if guard is not None and guard['event'] is None:
+            guard['host'].copy_(guard['flag'], non_blocking=True)
+            guard['event'] = torch.cuda.Event()
+            guard['event'].record()
     return y
 
 

@@ -8,6 +8,7 @@ precision and stay on stock PyTorch-ROCm ops; every 3x3 convolution of the resid
 a ``QuantConv2d`` and, in eval mode on the GPU, runs on the gfx950 kernels.
 """
 
+import warnings
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -74,6 +75,7 @@ def _is_resnet_stem(conv: nn.Conv2d, relu: nn.Module, pool: nn.Module, x: torch.
     def two(v):
         return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
     return (x.dim() == 4 and x.dtype == torch.float32 and x.shape[1] == 3 and x.shape[3] % 2 == 0 and x.shape[2] >= 8
+            and x.shape[3] >= 8 and x.data_ptr() % 8 == 0 and x.is_contiguous()
             and conv.out_channels == 64 and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.weight.dtype == torch.float32
             and two(pool.kernel_size) == (3, 3) and two(pool.stride) == (2, 2) and two(pool.padding) == (1, 1)
@@ -93,7 +95,16 @@ class _Stem(nn.Sequential):
             if FUSED_STEM and _is_resnet_stem(conv, relu, pool, x):
                 # conv + bias + ReLU + max-pool in one kernel (csrc/lsq_stem.hip): the 112x112x64 convolution
                 # output never goes to HBM, no channels-last copy of the input
-                return _hip.stem_conv_pool(x, w, b, STEM_SPLIT)
+                split = STEM_SPLIT
+                if split == 22 and _hip.stem_overflow_tripped(x.device):
+                    # an earlier batch had operands outside the fp16 split's domain (|value| >= 65504): its output held
+                    # inf / nan; from here on the bf16 split, which takes any finite input
+                    if not self.__dict__.get('_warned_split'):
+                        self.__dict__['_warned_split'] = True
+                        warnings.warn('lsq_stem_conv_pool: operands at or beyond 65504 seen; the stem now uses the three-term '
+                                      'bf16 split (STEM_SPLIT = 3). Outputs of the batches before this warning may hold inf / nan.')
+                    split = 3
+                return _hip.stem_conv_pool(x, w, b, split)
             # a per-channel bias commutes with max-pooling too: add it on the pooled (4x smaller) tensor.
             # MIOpen's 7x7 stride-2 convolution and the pooling are ~1.3x / ~1.9x faster in channels-last
             # (measured, scripts/stem_bench.py); the bias add writes the NCHW tensor the quantizer reads.

@@ -248,3 +248,36 @@ def test_full_size_fp_activation_layers(c, h, o, stride):
             z = torch.where(z > 0, z, prelu.weight.double() * z) + res[i:i + 32].double()
             ref[i:i + 32] = z.float()
     assert rel_err(y1, ref) <= TOL, rel_err(y1, ref)
+
+
+# ---------------------------------------------------------------------------------------------- stem: domain of the fp16 split
+def test_stem_fp16_split_reports_out_of_range_operands_and_the_model_falls_back():
+    """STEM_SPLIT = 22 (fp16 leading term) holds operands below 65504; a larger one is reported by the kernel through a
+    device flag (no host synchronisation on the way), after which the model's stem switches to the three-term bf16
+    split, whose output matches an fp64 convolution again."""
+    import warnings
+    import bench
+    hip = _hip()
+    hip.stem_overflow_reset(DEV)
+    try:
+        model = bench.build_model(bench.imagenet_arch('ls-2', 3), DEV)
+        x = torch.randn(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(DEV)
+        with torch.no_grad():
+            good = model.blocks[0](x)
+            torch.cuda.synchronize()
+            assert not hip.stem_overflow_tripped(DEV) and bool(torch.isfinite(good).all())
+            xb = x.clone()
+            xb[1, 2, 10, 11] = 1e5                                          # un-normalised 16-bit image data, say
+            model.blocks[0](xb)                                             # fp16 split: inf / nan around that pixel, which the
+            torch.cuda.synchronize()                                        # ReLU / max-pool can turn into wrong finite values
+            assert hip.stem_overflow_tripped(DEV)                           # the finished call has reported
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter('always')
+                again = model.blocks[0](xb)
+            assert any('65504' in str(c.message) for c in caught)
+            assert bool(torch.isfinite(again).all())
+            stem = model.blocks[0]
+            ref = torch.nn.functional.max_pool2d(torch.relu(stem[1](stem[0](xb.double().float()).float())), 3, 2, 1)
+            assert rel_err(again, ref) <= 1e-5
+    finally:
+        hip.stem_overflow_reset(DEV)
