@@ -1,70 +1,90 @@
-"""YAML config + command-line merge for the driver scripts.
+"""Command line + yaml -> one resolved config dictionary, for the driver scripts under ``examples/``.
 
-Interface of the reference's ``quant/common/parser.py``: ``get_base_argument_parser`` (:227-261, the six flags
-``--config --experiment-name --ngpus --skip-training --restore-experiment --init-from-checkpoint``),
-``parse_config`` (:196-224) and ``parse_common_fields`` (:160-193) with the same precedence: a restored
-experiment's ``config.yaml`` first, ``--config`` replaces it, command-line values override the file
-(``--ngpus`` beats ``environment.ngpus``), and the same two ``ValueError`` s.
+Same contract as the reference's ``quant/common/parser.py`` (flag names :227-261, precedence :160-224, the two
+``ValueError`` conditions :149-157) so its yaml files and command lines work unchanged, built differently: the flags
+are a table, and a single ``resolve`` applies the layers in order --
+
+    restored experiment's config.yaml  <  --config file  <  command-line flags  <  defaults for what is still missing
 """
 
 from argparse import ArgumentParser, Namespace
 from datetime import datetime
 from pathlib import Path
-from typing import Callable
+from typing import Any, Callable, Dict, Optional
 
 import torch
 import yaml
 
+#: flag -> (argparse keyword arguments, help text)
+FLAGS = {
+    '--config': (dict(type=str), 'Path to a yaml config file.'),
+    '--experiment-name': (dict(type=str, default=None), 'Name of the experiment.'),
+    '--ngpus': (dict(type=int, default=None), 'Number of GPUs. Use 0 for CPU.'),
+    '--skip-training': (dict(action='store_true', default=False),
+                        'Skip training and only run evaluation. Checkpoint must be passed in as well.'),
+    '--restore-experiment': (dict(type=str), 'Path to experiments directory to restore checkpoint from.'),
+    '--init-from-checkpoint': (dict(type=str), 'Path to model file to initialize model parameters.'),
+}
+
+
+def get_base_argument_parser(description: str) -> ArgumentParser:
+    parser = ArgumentParser(description)
+    for flag, (kwargs, text) in FLAGS.items():
+        parser.add_argument(flag, help=text, **kwargs)
+    return parser
+
 
 def _validate_args(args: Namespace) -> None:
-    if not args.restore_experiment and not args.config:
-        raise ValueError('--config must be specified if not restoring from experiment.')
-    if args.restore_experiment and args.init_from_checkpoint:
-        raise ValueError('Only one of --restore-experiment / --init-from-checkpoint can be set.')
+    """What cannot be resolved: nothing to read the model from, or two sources of initial weights."""
+    problems = {
+        '--config must be specified if not restoring from experiment.': not (args.restore_experiment or args.config),
+        'Only one of --restore-experiment / --init-from-checkpoint can be set.':
+            bool(args.restore_experiment and args.init_from_checkpoint),
+    }
+    for message, hit in problems.items():
+        if hit:
+            raise ValueError(message)
+
+
+def _load_yaml(path: Path) -> Dict[str, Any]:
+    with open(path) as handle:
+        return yaml.safe_load(handle)
+
+
+def _default_experiment_name(config_path: str, now: Optional[datetime] = None) -> str:
+    return f"{(now or datetime.now()).strftime('%b%d_%H-%M-%S')}_{Path(config_path).stem}"
 
 
 def parse_common_fields(args: Namespace, config: dict) -> None:
-    """Fill ``experiment_name``, ``environment``, ``skip_training`` and ``init_from_checkpoint`` from the flags."""
-    if args.experiment_name is not None:
-        config['experiment_name'] = args.experiment_name
-    else:
-        stamp = datetime.now().strftime('%b%d_%H-%M-%S')
-        config['experiment_name'] = f"{stamp}_{Path(config['config']).stem}"
-    if 'environment' not in config or 'platform' not in config['environment']:
-        config['environment'] = {'platform': 'local'}
-    if args.ngpus is not None:
-        config['environment']['ngpus'] = args.ngpus
-    if 'ngpus' not in config['environment']:
-        config['environment']['ngpus'] = 1 if torch.cuda.is_available() else 0
+    """Apply the command-line layer and the defaults to ``config`` in place (the reference's helper of the same name)."""
+    overrides = {'experiment_name': args.experiment_name, 'init_from_checkpoint': args.init_from_checkpoint or None}
+    config.update({key: value for key, value in overrides.items() if value is not None})
     config['skip_training'] = args.skip_training
-    if args.init_from_checkpoint:
-        config['init_from_checkpoint'] = args.init_from_checkpoint
+    if 'experiment_name' not in config or args.experiment_name is None:
+        config['experiment_name'] = args.experiment_name or _default_experiment_name(config['config'])
+    environment = config.get('environment')
+    if not isinstance(environment, dict) or 'platform' not in environment:
+        environment = config['environment'] = {'platform': 'local'}
+    if args.ngpus is not None:
+        environment['ngpus'] = args.ngpus
+    environment.setdefault('ngpus', 1 if torch.cuda.is_available() else 0)
 
 
-def parse_config(args: Namespace, validator: Callable[[Namespace], None] = _validate_args) -> dict:
-    """The resolved config: file contents with the command-line arguments applied on top."""
-    validator(args)
-    config: dict = {}
+def resolve(args: Namespace) -> dict:
+    """File layers, then flags, then defaults."""
+    layers = []
     if args.restore_experiment:
-        with open(Path(args.restore_experiment) / 'config.yaml') as f:
-            config = yaml.safe_load(f)
+        layers.append(_load_yaml(Path(args.restore_experiment) / 'config.yaml'))
     if args.config:
-        with open(args.config) as f:
-            config = yaml.safe_load(f)
-        config['config'] = args.config
+        layers.append(dict(_load_yaml(Path(args.config)), config=args.config))
+    config = dict(layers[-1]) if layers else {}              # (--config REPLACES a restored config, it does not merge)
     parse_common_fields(args, config)
     if args.restore_experiment:
         config['restore_experiment'] = args.restore_experiment
     return config
 
 
-def get_base_argument_parser(description: str) -> ArgumentParser:
-    parser = ArgumentParser(description)
-    parser.add_argument('--config', type=str, help='Path to a yaml config file.')
-    parser.add_argument('--experiment-name', type=str, default=None, help='Name of the experiment.')
-    parser.add_argument('--ngpus', type=int, default=None, help='Number of GPUs. Use 0 for CPU.')
-    parser.add_argument('--skip-training', default=False, action='store_true',
-                        help='Skip training and only run evaluation. Checkpoint must be passed in as well.')
-    parser.add_argument('--restore-experiment', type=str, help='Path to experiments directory to restore checkpoint from.')
-    parser.add_argument('--init-from-checkpoint', type=str, help='Path to model file to initialize model parameters.')
-    return parser
+def parse_config(args: Namespace, validator: Callable[[Namespace], None] = _validate_args) -> dict:
+    """The resolved config: file contents with the command-line arguments applied on top."""
+    validator(args)
+    return resolve(args)

@@ -69,5 +69,15 @@ def all_gather_logits(local: torch.Tensor, out: Optional[torch.Tensor] = None, g
 @torch.no_grad()
 def evaluate_sharded(model: torch.nn.Module, x_local: torch.Tensor, out: Optional[torch.Tensor] = None,
                      group=None, total: Optional[int] = None, always_collective: bool = False) -> torch.Tensor:
-    """One inference step: local forward on this rank's shard, then the all-gather of logits."""
-    return all_gather_logits(model(x_local), out, group, total, always_collective)
+    """One inference step: local forward on this rank's shard, then the all-gather of logits.
+
+    A batch smaller than the number of ranks leaves some ranks without a sample (``local_slice`` gives them an empty
+    shard): the kernels refuse empty batches, and a rank that raised would leave the others waiting in the
+    collective -- such a rank runs the model on ONE sample borrowed from its own padding (zeros of the input's
+    shape), to learn the width of the logits, and contributes no rows."""
+    if x_local.shape[0] == 0:
+        probe = model(x_local.new_zeros((1,) + tuple(x_local.shape[1:])))
+        local = probe[:0]
+    else:
+        local = model(x_local)
+    return all_gather_logits(local, out, group, total, always_collective)

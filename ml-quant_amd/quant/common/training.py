@@ -34,12 +34,13 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
     batch_idx = -1
     with torch.no_grad():
         for batch_idx, (data, target) in enumerate(test_loader):
-            data, target = data.to(device), target.to(device)
+            target = target.to(device)
             if sharded:
+                # the shard is cut on the host: only this rank's samples cross PCIe
                 part = local_slice(data.shape[0], dist.get_rank(), dist.get_world_size())
-                output = evaluate_sharded(model, data[part], total=data.shape[0])
+                output = evaluate_sharded(model, data[part].to(device), total=data.shape[0])
             else:
-                output = model(data)
+                output = model(data.to(device))
             for metric in metrics.values():
                 metric.update(output, target)
     for hook in hooks:

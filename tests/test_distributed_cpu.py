@@ -115,3 +115,42 @@ def test_local_slice_covers_batch():
     for n, w in ((12, 2), (13, 4), (2048, 8), (3, 8)):
         idx = [i for r in range(w) for i in range(n)[local_slice(n, r, w)]]
         assert idx == list(range(n))
+
+
+def _worker_small_batch(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'ml-quant_amd'), os.path.join(ROOT, 'tests', 'golden')):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import detgen
+    from quant.common.metrics import Top1Accuracy
+    from quant.common.training import evaluate
+    torch.set_num_threads(2)
+    model = _tiny_resnet()
+    # a "test set" whose last batch holds ONE sample: rank 1 gets an empty shard of it
+    xs = detgen.normal('dist.small', (5, 3, 16, 16))
+    ys = torch.tensor([1, 3, 5, 7, 9])
+
+    class Loader(list):
+        dataset = list(range(5))
+    loader = Loader([(xs[:4], ys[:4]), (xs[4:], ys[4:])])
+    metrics = {'Top-1 Accuracy': Top1Accuracy(accumulate=True)}
+    out = evaluate(model, loader, metrics, torch.device('cpu'), epoch=1)
+    with torch.no_grad():
+        full = model(xs)
+    want = float((full.argmax(dim=1) == ys).float().mean())
+    torch.save({'metric': out['Top-1 Accuracy'], 'want': want}, os.path.join(out_dir, f's{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluate_with_a_batch_smaller_than_the_world(tmp_path):
+    """The reference's DataParallel never hands a replica an empty batch; batch-sharded ranks can get one (a last batch
+    of one sample on two ranks).  The empty rank must still join the collective, and every rank must report the metric of
+    the whole set."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_small_batch, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), f's{r}.pt'))
+        assert abs(float(d['metric']) - d['want']) < 1e-6 or abs(float(d['metric']) - 100 * d['want']) < 1e-4, d
