@@ -63,7 +63,7 @@ def pmc_traffic_per_launch(entry):
     import csv
     import glob
     prefix = {'lsq_act_quant': 'aq_', 'lsq_xnor_conv2d': 'xnor_', 'lsq_signw_conv2d': 'signw_conv_'}.get(entry)
-    tables = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm_traffic.json')))
+    tables = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_hbm_traffic%s.json' % ('_fpact' if entry == 'lsq_signw_conv2d' else ''))))
     steps = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_per_step_summary%s.csv' % ('_fpact' if entry == 'lsq_signw_conv2d' else ''))))
     if not prefix or not tables or not steps:
         return None
@@ -113,12 +113,35 @@ MFMA_BF16_PEAK_T = 2500.0
 PATH_ROOFLINE_IMG_S = {'ls-2': 628e3, 'ls-T': 628e3, 'ls-1': 628e3, 'gf-2': 628e3, 'fp': 628e3}   # 8 TB/s / 12.74 MB
 
 
-def kernel_roofline(name, launches, ms, nbytes, ops):
+def pmc_mfma_busy(entry):
+    """Counter-based matrix-core utilisation of ``entry``'s kernels from the committed SQ counter passes
+    (scripts/capture_profiles.sh -> profiles/*_pmc_sq.json: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) per
+    layer shape, weighted by the shape's share of the forward); None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_sq.json')))
+    if not files:
+        return None
+    rows = [r for r in json.load(open(files[-1])).get('kernels', []) if r.get('entry') == entry]
+    if not rows:
+        return None
+    w = sum(r['count_in_forward'] * r['busy_cu_cycles'] for r in rows)
+    busy = sum(r['count_in_forward'] * r['busy_cu_cycles'] * r['mfma_busy_frac'] for r in rows) / max(w, 1e-30)
+    return {'mfma_busy_frac': busy, 'source': os.path.basename(files[-1]),
+            'per_shape': {r['shape']: round(r['mfma_busy_frac'], 4) for r in rows}}
+
+
+def kernel_roofline(name, launches, ms, nbytes, ops, survey_bytes=None):
     """The roofline entry of one path kernel: the bound SURVEY 8(d) assigns to it (quantizer: HBM; XNOR conv:
-    VALU popcount with HBM second; sign-weight conv: bf16 MFMA with both passes counted)."""
+    VALU popcount with HBM second; sign-weight conv: bf16 MFMA with both passes counted).  The HBM view of the
+    convolutions comes in both accountings: `frac` counts every operand the call must move once (the residual
+    operands of the fused epilogue included), `frac_survey_8d` SURVEY 8(d)'s input-once + output-once bytes."""
     sec = ms * 1e-3
     hbm = {'bound': 'hbm', 'achieved': nbytes / sec / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-           'frac': nbytes / sec / 1e9 / HBM_PEAK_GBPS}
+           'frac': nbytes / sec / 1e9 / HBM_PEAK_GBPS,
+           'bytes': 'input read once + output written once + residual operands of the fused epilogue read once'}
+    if survey_bytes is not None:
+        hbm['achieved_survey_8d'] = survey_bytes / sec / 1e9
+        hbm['frac_survey_8d'] = survey_bytes / sec / 1e9 / HBM_PEAK_GBPS
     if name == 'lsq_xnor_conv2d':
         # 3x3 layers over 64..512 channels run on v_mfma_i32_32x32x32_i8 (csrc/lsq_xnor_mfma.hip): integer MFMA bound,
         # 2 ops per binary MAC; the popcount kernel (other geometries) is priced against the same peak
@@ -133,6 +156,12 @@ def kernel_roofline(name, launches, ms, nbytes, ops):
              'note': 'bf16 hi + lo passes both counted (useful fraction = half)', 'secondary': hbm}
     else:
         r = hbm
+    if r.get('bound') == 'mfma':
+        busy = pmc_mfma_busy(name)
+        if busy:
+            r['mfma_busy_frac'] = busy['mfma_busy_frac']
+            r['mfma_busy_note'] = ('SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the kernel on its own, rocprofv3 --pmc '
+                                   'passes in profiles/' + busy['source'] + ', per layer shape: ' + json.dumps(busy['per_shape']))
     r.update(kernel=name, launches=launches, avg_launch_us=1e3 * ms / max(launches, 1))
     return r
 
@@ -222,6 +251,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--min-seconds', type=float, default=1.0,
+                    help='repeat the bracket of --steps timed steps until this much time has been timed')
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--cpu-sample', type=int, default=256, help='batch of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -269,35 +300,49 @@ def main():
         by_shape = _hip.drain_timing(by_tag=True)
         table = {}
         for (name, _tag), v in by_shape.items():
-            table[name] = tuple(a + b for a, b in zip(table.get(name, (0, 0.0, 0, 0)), v))
+            table[name] = tuple(a + b for a, b in zip(table.get(name, (0, 0.0, 0, 0, 0)), v))
         candidates = {k: v for k, v in table.items() if k in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d')}
         dominant = max(candidates, key=lambda k: candidates[k][1])
         _hip.enable_timing(True, only=[dominant])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # EXACTLY args.steps timed steps between the synchronisation points; events between groups of steps (none
-    # inside a step) give the per-step minimum / median
+    # Repetitions of EXACTLY args.steps timed steps, each bracketed by barrier + synchronize on both sides; as many
+    # repetitions as it takes to time at least args.min_seconds (a 20-step bracket is 0.06 s: too short for the clocks
+    # and the power state to settle).  value = all timed steps / the sum of the brackets' times (max over ranks per
+    # bracket).  Events between groups of steps (none inside a step) give the per-step minimum / median.
     per = max(1, args.steps // 10)
     groups = [per] * (args.steps // per) + ([args.steps % per] if args.steps % per else [])
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
-    t0 = time.perf_counter()
-    evs[0].record()
-    for i, n in enumerate(groups):
-        for k in range(n):
-            _hip.pause_timing(k != 0)
-            step()
-        evs[i + 1].record()
-    _hip.pause_timing(False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    group_ms = sorted(evs[i].elapsed_time(evs[i + 1]) / n for i, n in enumerate(groups))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, reps, group_ms, rep_ms = 0.0, 0, [], []
+    while True:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i, n in enumerate(groups):
+            for k in range(n):
+                _hip.pause_timing(k != 0)
+                step()
+            evs[i + 1].record()
+        _hip.pause_timing(False)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())                               # (every rank sees the same dt: same number of repetitions)
+        elapsed += dt
+        reps += 1
+        rep_ms.append(1e3 * dt / args.steps)
+        group_ms += [evs[i].elapsed_time(evs[i + 1]) / n for i, n in enumerate(groups)]
+        if elapsed >= args.min_seconds or reps >= 10000:
+            break
+    group_ms.sort()
+    steps_timed = reps * args.steps
     timed_table = _hip.drain_timing() if not args.no_roofline else {}
     _hip.enable_timing(False)
 
@@ -327,13 +372,15 @@ def main():
                              'per_link = received bytes / (world - 1) point-to-point xGMI links'}
 
     if rank == 0:
-        value = world * args.batch * args.steps / elapsed
+        value = world * args.batch * steps_timed / elapsed
         out = {
             'metric': 'images/sec ResNet-18 LS-1w/LS-2a 224x224 eval forward' if args.act == 'ls-2' else
                       f'images/sec ResNet-18 ls-1w/{args.act}-a 224x224 eval forward',
             'value': value, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'ms_per_step_min': group_ms[0], 'ms_per_step_median': group_ms[len(group_ms) // 2],
+            'steps_timed': steps_timed, 'repetitions': reps, 'timed_seconds': elapsed,
+            'ms_per_step': 1e3 * elapsed / steps_timed, 'ms_per_step_min': group_ms[0], 'ms_per_step_median': group_ms[len(group_ms) // 2],
+            'ms_per_step_best_repetition': min(rep_ms),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'i8 mfma on sign bits (exact integers) + f32', 'data': 'synthetic',
             'config': {'workload': f'ResNet-18 ImageNet ls-1 weight / {args.act} activation, '
@@ -345,8 +392,8 @@ def main():
                               'layers read and write once (SURVEY 8(d)); popcount roofline 376 k images/s (ls-2)',
         }
         if not args.no_roofline:
-            launches, ms, nbytes, ops = timed_table[dominant]               # events over the timed region
-            out['roofline'] = kernel_roofline(dominant, launches, ms, nbytes, ops)
+            out['roofline'] = kernel_roofline(dominant, *timed_table[dominant])     # events over the timed region
+            launches, nbytes = timed_table[dominant][0], timed_table[dominant][2]
             out['roofline']['measured'] = ('HIP events around every launch of this kernel in the first step of every group of '
                                            '%d steps of the timed region' % per)
             out['roofline']['traffic'] = None
@@ -366,12 +413,12 @@ def main():
                     kern[k]['algorithmic_bytes_per_launch'] = v[2] / max(v[0], 1)
             # per layer shape: which launches are output-bound (HBM) and which matrix-core-bound
             shapes = {}
-            for (name, tag), (cnt, ms, nb, ops) in sorted(by_shape.items(), key=lambda kv: str(kv[0])):
-                if tag is None or name not in ('lsq_act_quant', 'lsq_xnor_conv2d'):
+            for (name, tag), (cnt, ms, nb, ops, _sb) in sorted(by_shape.items(), key=lambda kv: str(kv[0])):
+                if tag is None or name not in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d'):
                     continue
                 row = {'launches': cnt, 'avg_launch_us': 1e3 * ms / cnt, 'algorithmic_GBps': nb / (ms * 1e-3) / 1e9}
                 if ops:
-                    row['T_binary_MAC_per_s'] = ops / (ms * 1e-3) / 1e12
+                    row['T_binary_MAC_per_s' if name == 'lsq_xnor_conv2d' else 'TFLOP_per_s'] = ops / (ms * 1e-3) / 1e12
                 shapes.setdefault(name, {})[tag] = row
             out['roofline']['kernels'] = kern
             out['roofline']['by_layer_shape'] = shapes

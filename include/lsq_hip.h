@@ -8,7 +8,9 @@
  *
  * Conventions
  *  - All pointers are DEVICE pointers owned by the caller (torch allocator); the library
- *    allocates nothing, keeps no global state and is re-entrant per stream.
+ *    allocates nothing and is re-entrant per stream.  The entry points below keep no state between calls; the only
+ *    process-wide variables in the library are the three test hooks of lsq_hip_debug.h (default off), which select
+ *    between implementations that return identical results.
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
  *  - Every function returns 0 on success, a negative LSQ_E_* code for an argument error,
  *    or a positive hipError_t if a launch failed.

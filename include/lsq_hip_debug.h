@@ -1,0 +1,31 @@
+/*
+ * lsq_hip_debug.h -- test hooks of liblsq_hip.so.  NOT part of the product ABI (lsq_hip.h): nothing on the
+ * inference path reads or needs them, the defaults (all 0) are what ships, and a maintainer binding the library into
+ * the reference would not declare them.
+ *
+ * They exist so that the parity tests can run the SAME call through an alternative implementation of one entry point
+ * and compare the results bit for bit (tests/test_gpu_parity.py: integer-MFMA vs popcount convolution, single-launch
+ * vs three-kernel quantizer, the quantizer's rare block / overflow paths on ordinary data).
+ *
+ * The switches are process-wide relaxed atomics: setting one while another thread has a call in flight makes THAT
+ * call take either implementation (both give identical results); there is no other interaction.  Each setter returns
+ * the previous value so that callers can restore it (quant._hip.debug_switches does, in a finally block).
+ */
+#ifndef LSQ_HIP_DEBUG_H_
+#define LSQ_HIP_DEBUG_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1: lsq_xnor_conv2d takes the popcount kernel for every geometry (default 0: integer-MFMA kernel where it applies) */
+int lsq_debug_xnor_impl(int popcount_only);
+/* 1: lsq_act_quant / lsq_solve_rows take the streaming three-kernel path for every shape (default 0) */
+int lsq_debug_force_streaming(int on);
+/* single-launch quantizer: 1 = every flagged bin through its block path, 2 = key list of 2048 entries (default 0) */
+int lsq_debug_fused_mode(int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQ_HIP_DEBUG_H_ */

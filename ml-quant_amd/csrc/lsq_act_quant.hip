@@ -25,6 +25,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "lsq_common.h"
 #include "lsq_solver_math.h"
 #include "lsq_act_fused.h"
@@ -1679,21 +1681,10 @@ int run(Args a, hipStream_t st) {
 
 using namespace lsq;
 
-// developer / test switch: 1 forces the streaming three-kernel path for every shape (the fused single-launch
-// path is otherwise taken whenever the row fits); not part of the public header
-static int g_force_streaming = 0, g_fused_debug = 0;
-extern "C" int lsq_debug_force_streaming(int on) {
-  const int old = g_force_streaming;
-  g_force_streaming = on;
-  return old;
-}
-// rare paths of the single-launch quantizer on ordinary data: 1 = every flagged bin through its block path,
-// 2 = key list of 2048 entries (most bins overflow to the block path)
-extern "C" int lsq_debug_fused_mode(int mode) {
-  const int old = g_fused_debug;
-  g_fused_debug = mode;
-  return old;
-}
+// test hooks (include/lsq_hip_debug.h, not part of the product ABI): relaxed process-wide atomics, default 0
+static std::atomic<int> g_force_streaming{0}, g_fused_debug{0};
+extern "C" int lsq_debug_force_streaming(int on) { return g_force_streaming.exchange(on, std::memory_order_relaxed); }
+extern "C" int lsq_debug_fused_mode(int mode) { return g_fused_debug.exchange(mode, std::memory_order_relaxed); }
 
 extern "C" int64_t lsq_act_plane_words(const lsq_conv_geom* g) {
   if (check_geom(g)) return -1;
@@ -1744,7 +1735,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   const int HW = g->H * g->W;
   const bool al16 = ((uintptr_t)x % 16) == 0, al8 = ((uintptr_t)x % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
-  if (solver && skip == 3 && !g_force_streaming) {
+  if (solver && skip == 3 && !g_force_streaming.load(std::memory_order_relaxed)) {
     // single launch with the sub-sample resident on chip (lsq_act_fused.hip) when the row fits
     FusedArgs f = {};
     f.x = x; f.row_elems = a.row_elems;
@@ -1752,7 +1743,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     f.pad_h = a.pad_h; f.pad_w = a.pad_w;
     f.alpha = clamp_alpha; f.pre_scale = pre_scale; f.pre_shift = pre_shift;
     f.planes = a.planes; f.plane_words = a.plane_words; f.row_words = a.row_words;
-    f.scales = scales; f.N = a.N; f.ternary = a.ternary; f.debug = g_fused_debug;
+    f.scales = scales; f.N = a.N; f.ternary = a.ternary; f.debug = g_fused_debug.load(std::memory_order_relaxed);
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
   }

@@ -17,6 +17,8 @@
 // for every out-of-image tap of a border pixel, which makes the result exact.
 
 #include "lsq_common.h"
+#include <atomic>
+
 #include "lsq_xnor_conv.h"
 
 #include <cstdlib>
@@ -244,9 +246,9 @@ int launch_kx(ConvArgs a, int groups, hipStream_t st) {
 
 using namespace lsq;
 
-static int g_force_popcount = 0;
-// test / profiling switch (not part of the contract): 1 = every geometry through the popcount kernel
-extern "C" void lsq_debug_xnor_impl(int popcount_only) { g_force_popcount = popcount_only; }
+// test hook (include/lsq_hip_debug.h, not part of the product ABI): 1 = every geometry through the popcount kernel
+static std::atomic<int> g_force_popcount{0};
+extern "C" int lsq_debug_xnor_impl(int popcount_only) { return g_force_popcount.exchange(popcount_only, std::memory_order_relaxed); }
 
 extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
                                const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
@@ -295,7 +297,7 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
       a.wscale = wscales + (long long)q * g->O;
       a.accumulate = first ? 0 : 1;
       a.final_pass = (q == kw_planes - 1 && p0 + np >= kx) ? 1 : 0;
-      int e = g_force_popcount ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
+      int e = g_force_popcount.load(std::memory_order_relaxed) ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
       if (e == kXnorMfmaNotEligible) e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
       if (e) return e;
       first = false;

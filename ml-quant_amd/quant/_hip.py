@@ -5,6 +5,7 @@ device pointers (``tensor.data_ptr()``) and the current HIP stream.  There is no
 eager fallback here: if the library is missing, or a call fails, an exception is raised.
 """
 
+import contextlib
 import ctypes
 import os
 import threading
@@ -73,6 +74,9 @@ def _declare(lib):
     lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     lib.lsq_pointwise_conv.restype = i32
     lib.lsq_pointwise_conv.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
+    for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode'):     # include/lsq_hip_debug.h
+        getattr(lib, hook).restype = i32
+        getattr(lib, hook).argtypes = [i32]
     lib.lsq_stem_conv_pool.restype = i32
     lib.lsq_stem_conv_pool.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]
 
@@ -153,23 +157,27 @@ def pause_timing(paused: bool = True) -> None:
 
 
 def drain_timing(by_tag: bool = False):
-    """{kernel: (launches, total_ms, total_algorithmic_bytes, total_ops)}; call after torch.cuda.synchronize().
-    ops = binary MACs (xnor conv) or bf16 FLOPs (sign-weight conv), 0 for the quantizer.  ``by_tag``: keys are
+    """{kernel: (launches, total_ms, total_algorithmic_bytes, total_ops, total_survey_bytes)}; call after
+    torch.cuda.synchronize().  ops = binary MACs (xnor conv) or bf16 FLOPs (sign-weight conv), 0 for the quantizer;
+    survey bytes = SURVEY 8(d)'s count (input once + output once, no residual operands).  ``by_tag``: keys are
     (kernel, tag) with the tag the call site attached (the layer's input channels and height)."""
     out = {}
     for name, recs in (_timing or {}).items():
         groups = {}
         for s, e, b in recs:
-            groups.setdefault((name, b[2]) if by_tag else name, []).append((s.elapsed_time(e), b[0], b[1]))
+            groups.setdefault((name, b[2]) if by_tag else name, []).append((s.elapsed_time(e), b[0], b[1], b[3]))
         for key, rows in groups.items():
-            out[key] = (len(rows), sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows))
+            out[key] = (len(rows), sum(r[0] for r in rows), sum(r[1] for r in rows), sum(r[2] for r in rows),
+                        sum(r[3] for r in rows))
         recs.clear()
     return out
 
 
 class _Timed:
-    def __init__(self, name, nbytes, ops=0, tag=None):
-        self.name, self.nbytes = name, (nbytes, ops, tag)
+    def __init__(self, name, nbytes, ops=0, tag=None, survey_bytes=None):
+        # nbytes: every operand the call must move once (residuals of a fused epilogue included);
+        # survey_bytes: SURVEY 8(d)'s definition for the path kernels (input read once + output written once)
+        self.name, self.nbytes = name, (nbytes, ops, tag, nbytes if survey_bytes is None else survey_bytes)
 
     def __enter__(self):
         self.on = _timing is not None and not _timing_paused and (_timing_only is None or self.name in _timing_only)
@@ -279,7 +287,8 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
     nres = (res_pre is not None) + (res_post is not None)
     # algorithmic bytes: planes read + fp32 output written + every residual operand of the fused epilogue read
-    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}'):
+    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
+                         geom.N * kx * m // 8 + 4 * y.numel()):
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
@@ -308,7 +317,8 @@ def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: to
     act, slope = _act(relu, prelu, geom.O)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
     nres = (res_pre is not None) + (res_post is not None)
-    with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel() * (1 + nres), flops):     # fp32 input read + fp32 output written + residuals read
+    with _on(x), _Timed('lsq_signw_conv2d', 4 * x.numel() + 4 * y.numel() * (1 + nres), flops, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
+                         4 * x.numel() + 4 * y.numel()):     # fp32 input read + fp32 output written (+ residuals read)
         check(lib().lsq_signw_conv2d(x.data_ptr(), float(alpha), None if pre is None else pre[0].data_ptr(),
                                      None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), ptr(wprep), wscales.shape[0],
                                      wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope), ptr(res_pre),
@@ -409,7 +419,27 @@ def pointwise_conv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return y
 
 
-def xnor_impl(popcount_only: bool) -> None:
-    """Test / profiling switch: route every XNOR convolution through the popcount kernel (True) or let the
-    dispatcher pick the integer-MFMA kernel where it applies (False, the default)."""
-    lib().lsq_debug_xnor_impl(int(bool(popcount_only)))
+def xnor_impl(popcount_only: bool) -> int:
+    """Test / profiling hook (include/lsq_hip_debug.h): route every XNOR convolution through the popcount kernel (True)
+    or let the dispatcher pick the integer-MFMA kernel where it applies (False, the default).  Returns the old value."""
+    return lib().lsq_debug_xnor_impl(int(bool(popcount_only)))
+
+
+@contextlib.contextmanager
+def debug_switches(xnor_popcount: Optional[bool] = None, force_streaming: Optional[bool] = None,
+                   fused_mode: Optional[int] = None):
+    """Set the library's test hooks (include/lsq_hip_debug.h) for the duration of a ``with`` block and restore the
+    previous values afterwards, whatever happens inside.  Process-wide: meant for single-threaded tests and scripts."""
+    handle = lib()
+    old = {}
+    try:
+        if xnor_popcount is not None:
+            old['lsq_debug_xnor_impl'] = handle.lsq_debug_xnor_impl(int(bool(xnor_popcount)))
+        if force_streaming is not None:
+            old['lsq_debug_force_streaming'] = handle.lsq_debug_force_streaming(int(bool(force_streaming)))
+        if fused_mode is not None:
+            old['lsq_debug_fused_mode'] = handle.lsq_debug_fused_mode(int(fused_mode))
+        yield
+    finally:
+        for name, value in old.items():
+            getattr(handle, name)(value)

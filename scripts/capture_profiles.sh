@@ -5,7 +5,7 @@
 # ceilings rest on (VALU issue rates, launch overhead) and the per-kernel micro-benchmark.
 # usage (through gpurun): scripts/capture_profiles.sh r02   -> files under gpurun_out/, copy to profiles/
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-tag=${1:-r02}; o=gpurun_out
+tag=${1:-r03}; o=gpurun_out
 mkdir -p $o
 python bench.py > $o/${tag}_bench_n1_ls2.json 2> $o/bench_ls2.err
 python bench.py --act fp --no-configs > $o/${tag}_bench_n1_fpact.json 2> $o/bench_fp.err
@@ -20,8 +20,17 @@ rm -rf $o/prof_fp
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --steps 30 --warmup 5 --cpu-sample 0 --no-configs > $o/prof_fp.log 2>&1
 python scripts/trace_summary.py $(ls -t $o/prof_fp/*/*kernel_trace.csv | head -1) 10 > $o/${tag}_rocprofv3_per_step_summary_fpact.csv
 scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic.json > $o/pmc.log 2>&1
-scripts/pmc_kernel.sh xnor_conv xnor python scripts/xnor_one.py 64 56 64 1 > $o/${tag}_pmc_xnor_conv_C64_H56.txt 2>&1
-scripts/pmc_kernel.sh xnor_conv xnor512 python scripts/xnor_one.py 512 7 512 1 > $o/${tag}_pmc_xnor_conv_C512_H7.txt 2>&1
+scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic_fpact.json --act fp > $o/pmc_fp.log 2>&1
+# SQ counters of the matrix-core kernels, one layer shape at a time (MFMA busy, VALU / LDS per MFMA, LDS conflicts, waits)
+specs=""
+for s in "64 56 64 1 4" "64 56 128 2 1" "128 28 128 1 3" "128 28 256 2 1" "256 14 256 1 3" "256 14 512 2 1" "512 7 512 1 3"; do
+  set -- $s; t="C$1_H$2_s$4"
+  scripts/pmc_kernel.sh xnor_mfma x_$t python scripts/xnor_one.py $1 $2 $3 $4 > $o/pmc_x_$t.txt 2>&1
+  scripts/pmc_kernel.sh signw_conv_lean s_$t python scripts/signw_one.py $1 $2 $3 $4 > $o/pmc_s_$t.txt 2>&1
+  specs="$specs lsq_xnor_conv2d:$t:$5:xnor_mfma:$o/pmc_x_$t lsq_signw_conv2d:$t:$5:signw_conv_lean:$o/pmc_s_$t"
+done
+scripts/pmc_kernel.sh stem_conv_pool stem python scripts/stem_one.py > $o/pmc_stem.txt 2>&1
+python scripts/pmc_sq_table.py $o/${tag}_pmc_sq.json $specs lsq_stem_conv_pool:224x224:1:stem_conv_pool:$o/pmc_stem > $o/${tag}_pmc_sq.txt 2>&1
 for u in valu_rates launch_overhead; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o /tmp/$u 2> $o/$u.build.log && /tmp/$u > $o/${tag}_ubench_$u.txt 2>&1
 done

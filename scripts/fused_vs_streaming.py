@@ -44,19 +44,11 @@ def make(dist, n, c, h, w, gen):
 
 
 def run(x, g, scheme, alpha, pre, force, mode=0):
-    lib = _hip.lib()
-    lib.lsq_debug_force_streaming.restype = ctypes.c_int
-    lib.lsq_debug_force_streaming.argtypes = [ctypes.c_int]
-    old = lib.lsq_debug_force_streaming(1 if force else 0)
-    lib.lsq_debug_fused_mode(mode)
-    try:
+    with _hip.debug_switches(force_streaming=force, fused_mode=mode):
         planes = torch.zeros(2 * _hip.act_plane_words(g), dtype=torch.int64, device='cuda')
         scales = torch.zeros((2, g.N), device='cuda')
         _hip.act_quant(x, g, scheme, 2, 3, alpha, planes, scales, pre=pre)
         torch.cuda.synchronize()
-    finally:
-        lib.lsq_debug_force_streaming(old)
-        lib.lsq_debug_fused_mode(0)
     return planes, scales
 
 

@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'lsq_hip.h')
 
 
-def declared_functions():
-    text = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+DEBUG_HEADER = os.path.join(ROOT, 'include', 'lsq_hip_debug.h')
+
+
+def declared_functions(header=HEADER):
+    text = re.sub(r'/\*.*?\*/', '', open(header).read(), flags=re.S)
     return sorted(set(re.findall(r'\b(lsq_[a-z0-9_]+)\s*\(', text)))
 
 
@@ -32,6 +35,30 @@ def test_header_declares_the_expected_entry_points():
         'lsq_abi_version', 'lsq_error_string', 'lsq_act_plane_words', 'lsq_weight_plane_words', 'lsq_solver_workspace_bytes',
         'lsq_act_quant', 'lsq_solve_rows', 'lsq_pack_weight', 'lsq_xnor_conv2d', 'lsq_signw_conv2d', 'lsq_signw_weight_bytes', 'lsq_signw_prepare_weight',
                 'lsq_pool_bias_relu_nhwc', 'lsq_stem_conv_pool', 'lsq_pointwise_conv'])
+
+
+def test_every_exported_symbol_is_declared_in_a_header(hip):
+    """The product ABI (lsq_hip.h) and the test hooks (lsq_hip_debug.h) together are ALL the library exports under the
+    lsq_ prefix: nothing undeclared can change what a call does."""
+    import shutil
+    import subprocess
+    nm = shutil.which('nm')
+    if nm is None:
+        pytest.skip('no nm on this machine')
+    out = subprocess.run([nm, '-D', '--defined-only', hip.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if ' T ' in line and line.split()[-1].startswith('lsq_')})
+    assert declared_functions(DEBUG_HEADER) == ['lsq_debug_force_streaming', 'lsq_debug_fused_mode', 'lsq_debug_xnor_impl']
+    assert exported == sorted(declared_functions() + declared_functions(DEBUG_HEADER)), exported
+
+
+def test_debug_switches_restore_the_previous_values(hip):
+    lib = hip.lib()
+    assert lib.lsq_debug_xnor_impl(0) == 0 and lib.lsq_debug_force_streaming(0) == 0 and lib.lsq_debug_fused_mode(0) == 0
+    with pytest.raises(RuntimeError):
+        with hip.debug_switches(xnor_popcount=True, force_streaming=True, fused_mode=2):
+            assert lib.lsq_debug_xnor_impl(1) == 1 and lib.lsq_debug_fused_mode(2) == 2
+            raise RuntimeError('a failing test body')
+    assert lib.lsq_debug_xnor_impl(0) == 0 and lib.lsq_debug_force_streaming(0) == 0 and lib.lsq_debug_fused_mode(0) == 0
 
 
 def test_library_exports_every_declared_symbol(hip):
