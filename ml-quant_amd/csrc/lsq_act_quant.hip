@@ -80,6 +80,7 @@ struct Args {
   int flat;                 // 1: dense [R][M] rows, no planes
   int ternary;
   int write_scale;          // sweep kernels: store mean|residual| as scale q
+  int csplit_log2;          // sweep kernels: 2^csplit_log2 lanes share one (64 channels x VEC pixels) item
   unsigned char* ws;        // workspace (kWsRow bytes per row)
 };
 
@@ -303,20 +304,30 @@ __device__ __forceinline__ void emit_subsample(const float (&x)[VEC], unsigned r
 
 // The lane = pixel(s), loop over 64 channels sweep shared by the pack passes and the gather pass.
 // body(cc, x[VEC], rem) is called for every channel of the item with the clamped values.
-template <int VEC, bool NEED_REM, class Begin, class Body, class End>
+// SPLIT (round 3): a row with fewer items than threads (small images: 32 x 32 and below) used to leave most of the
+// workgroup idle while every busy lane walked its 64 channels in a chain of dependent load batches -- 20 us per
+// launch on CIFAR-sized rows, latency, not bandwidth.  With SPLIT 2^csplit_log2 consecutive lanes share an item:
+// each walks `cper` = 64 >> csplit_log2 channels from its own base pointer (uniform loop bounds and bit positions,
+// exactly the code of the unsplit case), and `end` shifts the lane's partial word to its place and ORs the lanes'
+// words together (they sit in one wave and leave the loop together).
+template <int VEC, bool NEED_REM, bool SPLIT, class Begin, class Body, class End>
 __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict__ xrow, Begin begin, Body body, End end) {
   const int HW = a.H * a.W;
   const int PV = (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   const unsigned skip = (unsigned)a.skip;
   const unsigned step = (unsigned)(HW % a.skip);
-  for (int item = threadIdx.x; item < items; item += kThreads) {
+  const int csl = SPLIT ? a.csplit_log2 : 0, cs = 1 << csl;
+  const int part = SPLIT ? (int)(threadIdx.x & (cs - 1)) : 0;
+  const int cper = 64 >> csl;
+  for (int item = threadIdx.x >> csl; item < items; item += kThreads >> csl) {
     const int j = item / PV;
     const int p = (item - j * PV) * VEC;
     const int grp = j / a.Gg;
     const int jj = j - grp * a.Gg;
-    const int c0 = grp * a.cg + jj * 64;
-    const int nch = min(64, a.cg - jj * 64);
+    const int cfirst = part * cper;                         // the lane's first channel inside the 64-channel word
+    const int c0 = grp * a.cg + jj * 64 + cfirst;
+    const int nch = max(0, min(cper, a.cg - jj * 64 - cfirst));
     const float* src = xrow + (long long)c0 * HW + p;
     unsigned rem = NEED_REM ? (unsigned)(((long long)c0 * HW + p) % (long long)skip) : 0u;
     begin();
@@ -354,7 +365,7 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
 #pragma unroll
             for (int v = 0; v < VEC; ++v) x[v] = clamp_sym(vals[u][v], a.alpha);
           }
-          body(cc, x, rem);
+          body(cc, x, rem);             // (cc: bit position relative to the lane's first channel)
           if constexpr (NEED_REM) {
             rem += step;
             if (rem >= skip) rem -= skip;
@@ -362,11 +373,11 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
         }
       }
     }
-    end(j, p);
+    end(j, p, cfirst, cs);
   }
 }
 
-template <int VEC, bool HIST, int QM, class L>
+template <int VEC, bool HIST, int QM, bool SPLIT, class L>
 __device__ __forceinline__ PassOut pack_pass(L* lds, const float* __restrict__ xrow, unsigned long long* __restrict__ prow, int q) {
   const Args a = lds->args;              // registers (SGPRs): nothing below re-reads LDS for it
   const Chain ch = load_chain(lds, q);
@@ -375,7 +386,7 @@ __device__ __forceinline__ PassOut pack_pass(L* lds, const float* __restrict__ x
   unsigned mk = kNoKey;
   unsigned long long word[VEC];
   float facc[VEC];            // fp32 over one 64-channel column, folded into fp64 per item
-  sweep_row<VEC, HIST>(
+  sweep_row<VEC, HIST, SPLIT>(
       a, xrow,
       [&]() {
 #pragma unroll
@@ -401,14 +412,20 @@ __device__ __forceinline__ PassOut pack_pass(L* lds, const float* __restrict__ x
           });
         }
       },
-      [&](int j, int p) {
+      [&](int j, int p, int cfirst, int cs) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           acc += (double)facc[v];
+          unsigned long long wd = word[v];
+          if constexpr (SPLIT) {
+            wd <<= cfirst;                             // the lane's channels start at bit cfirst of the word
+            for (int d = 1; d < cs; d <<= 1)          // the lanes that share the item each hold some of its channels' bits
+              wd |= ((unsigned long long)(unsigned)__shfl_xor((int)(wd >> 32), d) << 32) | (unsigned)__shfl_xor((int)(unsigned)wd, d);
+          }
           const int pix = p + v;
           const int h = pix / a.W;
           const int w = pix - h * a.W;
-          prow[((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w] = word[v];
+          if (!SPLIT || cfirst == 0) prow[((long long)j * a.Hp + h + a.pad_h) * a.Wp + w + a.pad_w] = wd;
         }
       });
   PassOut out;
@@ -1540,7 +1557,9 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
     po = flat_pass<HIST, QM>(lds, xrow, q);
   } else {
     unsigned long long* prow = a.planes + (long long)q * a.plane_words + (long long)row * a.row_words;
-    po = pack_pass<VEC, HIST, QM>(lds, xrow, prow, q);
+    // (the split variant only where it is used: 8- and 16-byte loads; one pixel per lane has nothing to split)
+    if (VEC > 1 && a.csplit_log2 > 0) po = pack_pass<VEC, HIST, QM, (VEC > 1)>(lds, xrow, prow, q);
+    else po = pack_pass<VEC, HIST, QM, false>(lds, xrow, prow, q);
   }
   LSQ_MARK(1);
   // row sum (and, for the histogram sweep, the smallest key) in one LDS exchange
@@ -1658,6 +1677,18 @@ int launch_sweep(const Args& a, int q, bool hist, hipStream_t st) {
 // the whole sequence for one batch of rows
 template <int VEC>
 int run(Args a, hipStream_t st) {
+  // lanes per item: as many as leave no thread idle, as long as a lane's share of the 64 channels is still a full
+  // batch of loads (32 / VEC channels)
+  if (!a.flat) {
+    const long long items = (long long)a.Gt * ((a.H * a.W + VEC - 1) / VEC);
+    int csl = 0;
+    if (VEC > 1)                                           // (one pixel per lane: 32 channels per batch, nothing to split)
+      while ((items << (csl + 1)) <= kThreads && (64 >> (csl + 1)) >= 32 / VEC) ++csl;
+    a.csplit_log2 = csl;
+#ifdef LSQ_TUNE
+    if (const char* e = getenv("LSQ_CSPLIT")) a.csplit_log2 = atoi(e) < csl ? atoi(e) : csl;
+#endif
+  }
   const bool solver = (a.scheme == LSQ_SCHEME_LS2 || a.scheme == LSQ_SCHEME_LST) && !a.forced;
   if (a.forced) {
     hipError_t e = hipMemcpyAsync(a.scales, a.forced, sizeof(float) * (size_t)a.k * a.N, hipMemcpyDeviceToDevice, st);
@@ -1747,8 +1778,10 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
   }
-  if (HW % 4 == 0 && al16 && (long long)a.Gt * (HW / 4) >= 512) return run<4>(a, st);
-  if (HW % 2 == 0 && al8 && (long long)a.Gt * (HW / 2) >= 512) return run<2>(a, st);
+  // widest loads the image allows; rows with fewer items than threads split the 64 channels of an item over lanes
+  // (run<VEC>), so small images take 16-byte loads too
+  if (HW % 4 == 0 && al16 && (long long)a.Gt * (HW / 4) >= 16) return run<4>(a, st);
+  if (HW % 2 == 0 && al8 && (long long)a.Gt * (HW / 2) >= 16) return run<2>(a, st);
   return run<1>(a, st);
 }
 
