@@ -187,8 +187,10 @@ def timed_forward(fn, steps, warmup, chunks=10):
     return elapsed, ms[0], ms[len(ms) // 2]
 
 
-def config_leg(tag, model, x, steps, warmup, workload, cpu_reference_img_s=None):
-    """One of the other single-GPU configs of BASELINE.json as a short leg of the same process."""
+def config_leg(tag, model, x, steps, warmup, workload, cpu_reference_img_s=None, graph=False):
+    """One of the other single-GPU configs of BASELINE.json as a short leg of the same process.  ``graph``: the
+    launch-bound configurations (small images / batches: tens of microseconds of GPU work per launch) are also timed as
+    ONE HIP-graph replay per forward (quant/common/graph_replay.py); `value` is the faster of the two, both are reported."""
     from quant import _hip
     with torch.no_grad():
         fn = lambda: model(x)      # noqa: E731
@@ -203,7 +205,20 @@ def config_leg(tag, model, x, steps, warmup, workload, cpu_reference_img_s=None)
         elapsed, ms_min, ms_med = timed_forward(fn, steps, 2)
     path = {k: v for k, v in table.items() if k in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d')}
     out = {'workload': workload, 'batch': x.shape[0], 'steps': steps, 'value': x.shape[0] * steps / elapsed, 'unit': 'images/sec',
-           'ms_per_step': 1e3 * elapsed / steps, 'ms_per_step_min': ms_min, 'ms_per_step_median': ms_med}
+           'ms_per_step': 1e3 * elapsed / steps, 'ms_per_step_min': ms_min, 'ms_per_step_median': ms_med, 'launch': 'eager'}
+    if graph:
+        from quant.common.graph_replay import GraphedForward
+        with torch.no_grad():
+            eager = model(x).clone()
+        fwd = GraphedForward(model, x)
+        same = bool(torch.equal(fwd.replay(), eager))
+        g_elapsed, g_min, g_med = timed_forward(fwd.replay, steps, 2)
+        out['eager'] = {'value': out['value'], 'ms_per_step': out['ms_per_step']}
+        out['graph'] = {'value': x.shape[0] * steps / g_elapsed, 'ms_per_step': 1e3 * g_elapsed / steps, 'ms_per_step_min': g_min,
+                        'ms_per_step_median': g_med, 'output_equals_eager': same}
+        if same and g_elapsed < elapsed:
+            out.update(value=out['graph']['value'], ms_per_step=out['graph']['ms_per_step'], ms_per_step_min=g_min,
+                       ms_per_step_median=g_med, launch='one HIP-graph replay per forward')
     if path:
         dom = max(path, key=lambda k: path[k][1])
         out['roofline'] = kernel_roofline(dom, *path[dom])
@@ -438,12 +453,12 @@ def main():
             m = build_model(cifar_arch(), device)
             xc = torch.randn(100, 3, 32, 32, generator=torch.Generator().manual_seed(0)).to(device)
             cfg['cifar100_ls1_kd_b100'] = config_leg('cifar', m, xc, 100, 5, 'ResNet-18 CIFAR-100 cifar100_ls1_kd (ls-1 weights and '
-                                                     'activations, clamp 2), synthetic 3x32x32, batch 100 (yaml test_batch_size)', 192.6)
+                                                     'activations, clamp 2), synthetic 3x32x32, batch 100 (yaml test_batch_size)', 192.6, graph=True)
             del m
             m = build_lenet(device)
             xm = torch.randn(64, 1, 28, 28, generator=torch.Generator().manual_seed(0)).to(device)
             cfg['mnist_lenet_ls1w_fpa_b64'] = config_leg('lenet', m, xm, 200, 5, 'LeNet-5 mnist_ls1_weight_fp_activation, synthetic '
-                                                         '1x28x28, batch 64', 19048.0)
+                                                         '1x28x28, batch 64', 19048.0, graph=True)
             out['configs'] = cfg
             out['configs_note'] = ('value = images/sec of the eval forward, inputs resident in HBM; reference_cpu_images_per_sec_survey = '
                                    'the reference itself on the 8 build-container cores (SURVEY section 6)')

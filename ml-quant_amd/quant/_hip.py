@@ -392,7 +392,9 @@ def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: 
     hp, wp = (hc - 1) // 2 + 1, (wc - 1) // 2 + 1
     y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device)
     flops = 2 * (6 if split == 3 else 3) * n * 64 * hc * wc * 147      # 16-bit MFMA passes issued
-    guard = _stem_guard_state(x.device) if split == 22 else None
+    # (no guard while a HIP graph is being captured: the event / pinned-copy bookkeeping is host state of ONE call;
+    #  the warm-up forwards in front of a capture run with it)
+    guard = _stem_guard_state(x.device) if split == 22 and not torch.cuda.is_current_stream_capturing() else None
     if guard is not None:
         stem_overflow_tripped(x.device)                                   # (collect a finished report before the flag is reused)
     with _on(x), _Timed('lsq_stem_conv_pool', 4 * x.numel() + 4 * y.numel(), flops):

@@ -96,7 +96,7 @@ class _Stem(nn.Sequential):
                 # conv + bias + ReLU + max-pool in one kernel (csrc/lsq_stem.hip): the 112x112x64 convolution
                 # output never goes to HBM, no channels-last copy of the input
                 split = STEM_SPLIT
-                if split == 22 and _hip.stem_overflow_tripped(x.device):
+                if split == 22 and not torch.cuda.is_current_stream_capturing() and _hip.stem_overflow_tripped(x.device):
                     # an earlier batch had operands outside the fp16 split's domain (|value| >= 65504): its output held
                     # inf / nan; from here on the bf16 split, which takes any finite input
                     if not self.__dict__.get('_warned_split'):

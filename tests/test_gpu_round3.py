@@ -281,3 +281,20 @@ def test_stem_fp16_split_reports_out_of_range_operands_and_the_model_falls_back(
             assert rel_err(again, ref) <= 1e-5
     finally:
         hip.stem_overflow_reset(DEV)
+
+
+# ---------------------------------------------------------------------------------------------- HIP-graph replay
+def test_graph_replay_equals_eager_forward():
+    """quant/common/graph_replay.py: a CIFAR-sized quantized ResNet captured in a HIP graph returns the eager forward's
+    logits bit for bit, also for a second input copied into the static buffer."""
+    import bench
+    from quant.common.graph_replay import GraphedForward
+    model = bench.build_model(bench.cifar_arch(), DEV)
+    x1 = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to(DEV)
+    x2 = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(2)).to(DEV)
+    with torch.no_grad():
+        e1, e2 = model(x1).clone(), model(x2).clone()
+    fwd = GraphedForward(model, x1)
+    assert torch.equal(fwd(x1), e1)
+    assert torch.equal(fwd(x2), e2)
+    assert torch.equal(fwd(x1), e1)
