@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void pointwise_all_kernel(PwArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[64][kPitch];      // [pixel][channel]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const long long p0 = (long long)blockIdx.x * 64;
+  const int ob = (int)blockIdx.y * (NOT * 64);           // (few pixel tiles: the out-channels are spread over blockIdx.y)
   const int HoWo = a.Ho * a.Wo;
   const long long HW = (long long)a.H * a.W;
   const float* __restrict__ xsrc = a.x;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void pointwise_all_kernel(PwArgs a) {
   };
   f32x4 wq[4];
   auto load_w = [&](int t, int c0) {
-    const float* wsrc = a.w + (long long)(t * 64) * a.C + c0;
+    const float* wsrc = a.w + (long long)(ob + t * 64) * a.C + c0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) wq[k] = *reinterpret_cast<const f32x4*>(wsrc + (long long)(16 * k) * a.C + woff);
   };
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void pointwise_all_kernel(PwArgs a) {
   // lane: out-channel 64 t + mt * 32 + col, pixels p0 + nt * 32 + (reg & 3) + 8 (reg >> 2) + 4 g
 #pragma unroll
   for (int t = 0; t < NOT; ++t) {
-    const int o = 64 * t + mt * 32 + col;
+    const int o = ob + 64 * t + mt * 32 + col;
     const float b = a.bias ? a.bias[o] : 0.f;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -305,8 +306,15 @@ extern "C" int lsq_pointwise_conv(const float* x, int N, int C, int H, int W, co
   const int n_ot = O / 64;
   const bool pair_ok = stride != 2 || (a.Wo & 1) || (W & 1) == 0;
   if (n_ot <= 8 && (n_ot & (n_ot - 1)) == 0 && pair_ok) {
-    const dim3 grid((unsigned)blocks);
-    switch (n_ot) {
+    // out-channel tiles per workgroup: all of them (x gathered once) unless that leaves CUs without a workgroup
+    int per_wg = n_ot;
+    long long min_wgs = 256;
+#ifdef LSQ_TUNE
+    if (const char* e = getenv("LSQ_PW_MINWG")) min_wgs = atoll(e);
+#endif
+    while (per_wg > 1 && blocks * (n_ot / per_wg) < min_wgs) per_wg >>= 1;
+    const dim3 grid((unsigned)blocks, (unsigned)(n_ot / per_wg));
+    switch (per_wg) {
       case 1: launch_all<1>(a, grid, (hipStream_t)stream); break;
       case 2: launch_all<2>(a, grid, (hipStream_t)stream); break;
       case 4: launch_all<4>(a, grid, (hipStream_t)stream); break;
