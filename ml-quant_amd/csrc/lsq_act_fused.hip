@@ -1323,10 +1323,20 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
   const long long M = a.row_elems;
   if (M + 2 >= (1ll << 31) || M % 4 != 0 || HW < 4 || ((uintptr_t)a.x % 16) != 0) return kFusedNotEligible;
   constexpr int T = 512;
-  // pass 2: the widest per-lane vector that still gives every lane an item
+  // pass 2, pixels per lane (measured on the four ResNet-18 shapes, scripts/kbench.py under LSQ_FUSED_VEC): four
+  // when that is a single round of items (every load 16 bytes; idle lanes cost less than 4-byte loads, each a full
+  // address pass of the load path) or many rounds, two for the 1..4 rounds in between (56 x 56 x 64: 784 four-pixel
+  // items on 512 lanes are two rounds with the second half empty)
   int vec = 1;
-  if (HW % 4 == 0 && (long long)a.Gt * (HW / 4) >= T) vec = 4;
-  else if (HW % 2 == 0 && (long long)a.Gt * (HW / 2) >= T) vec = 2;
+  const long long items4 = (long long)a.Gt * (HW / 4);
+  if (HW % 4 == 0 && (items4 <= T || items4 >= 4 * T)) vec = 4;
+  else if (HW % 2 == 0) vec = 2;
+#ifdef LSQ_TUNE
+  if (const char* e = getenv("LSQ_FUSED_VEC")) {
+    const int v = atoi(e);
+    if ((v == 4 || v == 2 || v == 1) && HW % v == 0) vec = v;
+  }
+#endif
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
   if (need <= 5) return launch<T, 5>(a, vec, st);
