@@ -73,7 +73,8 @@ def main():
             pre = ((0.5 + torch.rand(c, device=dev)).contiguous(), (torch.randn(c, device=dev) * 0.3).contiguous())
         tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales, pre=pre), args.iters)
         tc = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), args.iters)
-        tf = timeit(lambda: _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y), args.iters)
+        wprep = _hip.signw_prepare_weight(wbits, 1, g)      # (the prepared weight image: the fast path, as the modules use it)
+        tf = timeit(lambda: _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y, wprep=wprep), args.iters)
         m = c * h * h
         qbytes = n * (4 * m + k * m // 8)
         macs = n * o * ho * wo * c * 9 * k
