@@ -67,16 +67,22 @@ def pmc_traffic_per_launch(entry):
     steps = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_per_step_summary%s.csv' % ('_fpact' if entry == 'lsq_signw_conv2d' else ''))))
     if not prefix or not tables or not steps:
         return None
+    def norm(name):                # "<namespace junk>::<kernel><...> grid=<threads>" -> "<kernel><...>" (None: another kernel)
+        name = name.split(' grid=')[0]
+        i = name.find(prefix)
+        return name[i:] if i >= 0 else None
     per_kernel = {}
-    for name, v in json.load(open(tables[-1]))['kernels'].items():       # rows: "<kernel> grid=<threads>"
-        if name.startswith(prefix):
-            per_kernel.setdefault(name.split(' grid=')[0], []).append(1e6 * (v['hbm_read_MB_corrected'] + v['hbm_write_MB']))
+    for name, v in json.load(open(tables[-1]))['kernels'].items():
+        if norm(name):
+            per_kernel.setdefault(norm(name), []).append(1e6 * (v['hbm_read_MB_corrected'] + v['hbm_write_MB']))
     total = launches = 0.0
     with open(steps[-1]) as f:
         next(f)
         for row in csv.DictReader(f):
-            kname = row['kernel']
-            match = [k for k in per_kernel if kname.startswith(k[:len(kname)]) or k.startswith(kname.split('(')[0])]
+            kname = norm(row['kernel'].split('(lsq')[0])                 # (the trace summary cuts names at 40 characters)
+            if not kname:
+                continue
+            match = [k for k in per_kernel if k.startswith(kname) or kname.startswith(k)]
             if match:
                 total += float(row['launches_per_step']) * sum(per_kernel[match[0]]) / len(per_kernel[match[0]])
                 launches += float(row['launches_per_step'])
