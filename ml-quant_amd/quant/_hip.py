@@ -314,6 +314,11 @@ def signw_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wscales: to
                  wprep: Optional[torch.Tensor] = None) -> None:
     """``wprep``: signw_prepare_weight(wbits, ...) of the same weights and geometry (same result, 3x3 fast path)."""
     x = _f32c(x)
+    if wprep is not None:              # (the image depends on channels, out-channels, taps and planes only: any batch / image size)
+        want = lib().lsq_signw_weight_bytes(ctypes.byref(geom), wscales.shape[0])
+        if wprep.dtype != torch.uint8 or wprep.numel() != want or wprep.device != x.device:
+            raise ValueError(f'wprep: expected {want} bytes of signw_prepare_weight output on {x.device} for this geometry, '
+                             f'got {wprep.numel()} x {wprep.dtype} on {wprep.device}')
     act, slope = _act(relu, prelu, geom.O)
     flops = 2 * 2 * y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * wscales.shape[0]   # hi + lo passes
     nres = (res_pre is not None) + (res_post is not None)

@@ -110,6 +110,18 @@ def test_signw_prepare_weight_declines_other_geometries():
         g = hip.make_geom(2, c, 8, 8, 32, kh, kw_, (1, 1), (1, 1), (1, 1), groups)
         assert hip.lib().lsq_signw_weight_bytes(g, 1) == 0
         assert hip.signw_prepare_weight(wbits, 1, g) is None
+    # an image prepared for another layer is refused on the host (it would be read as the wrong weights)
+    g64 = hip.make_geom(2, 64, 8, 8, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+    g128 = hip.make_geom(2, 64, 8, 8, 128, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+    w = torch.randn(128, 64, 3, 3, device=DEV)
+    wsc = w.abs().mean(dim=(1, 2, 3)).view(1, -1).contiguous()
+    wb128, _ = hip.pack_weight(w, g128, wsc)
+    wb64, _ = hip.pack_weight(w[:64].contiguous(), g64, wsc[:, :64].contiguous())
+    prep64 = hip.signw_prepare_weight(wb64, 1, g64)
+    x = torch.randn(2, 64, 8, 8, device=DEV)
+    y = torch.empty(2, 128, 8, 8, device=DEV)
+    with pytest.raises(ValueError, match='wprep'):
+        hip.signw_conv2d(x, 2.0, wb128, wsc, None, g128, y, wprep=prep64)
 
 
 # ---------------------------------------------------------------------------------------------- train-mode step on the device
