@@ -290,8 +290,19 @@ def main():
     device = torch.device('cuda', local)
     if 'RANK' in os.environ:                       # launched by torchrun (also with one rank): RCCL process group
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
-        dist.barrier()
+        # RCCL prints a version banner to the process's stdout when its first communicator comes up; stdout is for the
+        # ONE JSON line, so file descriptor 1 points at stderr while the group initialises
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=device)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from quant import _hip
     from quant.common.sharded_eval import all_gather_logits, evaluate_sharded
