@@ -163,13 +163,14 @@ def test_fp_fp_on_device_is_plain_conv2d():
 # ---------------------------------------------------------------------------------------------- full size: what bench.py runs
 def _bench_model(act):
     import bench
-    arch = bench.imagenet_arch('ls-2', 3) if act == 'ls-2' else bench.imagenet_arch('fp', 2)
+    arch = bench.imagenet_arch('ls-2', 3) if act == 'ls-2' else bench.imagenet_arch(act, 2)
     return bench.build_model(arch, DEV)
 
 
-@pytest.mark.parametrize('act', ['ls-2', 'fp'])
+@pytest.mark.parametrize('act', ['ls-2', 'fp', 'ls-1', 'ls-T', 'gf-2'])
 def test_full_size_whole_network(act):
-    """The benchmark's own workload -- ResNet-18 ImageNet, ls-1 weights, ls-2 (or fp) activations, batch 256 of
+    """The benchmark's own workload -- ResNet-18 ImageNet, ls-1 weights, ls-2 (or fp / ls-1 / ls-T / gf-2: the
+    reference's other four quantized ImageNet configurations, `bench.py --act`) activations, batch 256 of
     3 x 224 x 224 (intent of the reference's tests/models/test_resnet.py:112-136 at BASELINE size): deterministic,
     per-sample independent (rows 40:48 alone == rows 40:48 of the batch, bit for bit), and every one of the 16
     quantized layers checked in place on three rows of the batch (module-by-module path, forward hooks): the solved v1
@@ -214,6 +215,21 @@ def test_full_size_whole_network(act):
                 want = E.solve_rows(xc.reshape(len(rows), -1).cpu().numpy(), False, 3)
                 assert np.array_equal(scales[0].cpu().numpy(), want), (li, scales[0], want)
                 xq = P.quant_ls2(xc, scales[0], scales[1])[2]
+            elif act == 'ls-T':
+                want = E.solve_rows(xc.reshape(len(rows), -1).cpu().numpy(), True, 3)
+                assert np.array_equal(scales[0].cpu().numpy(), want), (li, scales[0], want)
+                xq = P.quant_lst(xc, scales[0])[1]
+            elif act == 'ls-1':                                             # v1 = mean |x| (fp64 sum on the device, fp32 nested means in the reference)
+                want = xc.double().abs().reshape(len(rows), -1).mean(dim=1)
+                assert torch.allclose(scales[0].double(), want, rtol=1e-6, atol=0), (li, scales[0], want)
+                xq = P.quant_ls1(xc, scales[0])[1]
+            elif act == 'gf-2':                                             # greedy: v1 = mean |x|, v2 = mean |x - v1 b1| with the device's v1
+                flat = xc.double().reshape(len(rows), -1)
+                want1 = flat.abs().mean(dim=1)
+                want2 = (flat - scales[0].double().view(-1, 1) * P.pm1(flat)).abs().mean(dim=1)
+                assert torch.allclose(scales[0].double(), want1, rtol=1e-6, atol=0), (li, scales[0], want1)
+                assert torch.allclose(scales[1].double(), want2, rtol=1e-6, atol=0), (li, scales[1], want2)
+                xq = P.quant_gf(xc, 2, [scales[0], scales[1]])[1]
             else:
                 xq = xc
             wq = conv.w_approximate.v1.view(-1, 1, 1, 1) * P.pm1(conv.weight)
