@@ -355,15 +355,18 @@ def _stem_guard_state(device):
     st = _stem_guard.get(idx)
     if st is None:
         st = _stem_guard[idx] = {'flag': torch.zeros((1,), dtype=torch.int32, device=torch.device('cuda', idx)),
-                                 'host': torch.zeros((1,), dtype=torch.int32).pin_memory(), 'event': None, 'tripped': False}
+                                 'host': torch.zeros((1,), dtype=torch.int32).pin_memory(), 'event': None, 'tripped': False,
+                                 'calls': 0}
     return st
 
 
 def stem_overflow_tripped(device) -> bool:
     """True once a FINISHED stem_conv_pool(split=22) call on ``device`` has reported an operand outside the fp16 split's
-    domain (|value| >= 65504 or NaN).  Never blocks: the kernel raises a device flag, its copy to pinned host memory
-    rides on the launch stream and is looked at only when its event has completed -- so the report arrives a call or
-    two after the offending one (whose output holds inf / nan).  Callers switch to split 3 (any finite input) then."""
+    domain (|value| >= 65504 or NaN).  Never blocks: the kernel raises a STICKY device flag; its copy to pinned host
+    memory rides on the launch stream after the first call and then after every 16th (a copy is a launch of its own:
+    4 us per forward if made every time) and is looked at only when its event has completed -- so the report arrives
+    up to 16 calls after the offending one (whose output holds inf / nan).  Callers switch to split 3 (any finite
+    input) then."""
     st = _stem_guard_state(device)
     ev = st['event']
     if ev is not None and ev.query():
@@ -377,7 +380,7 @@ def stem_overflow_reset(device) -> None:
     """Forget an earlier report (after the caller has dealt with it); waits for the device."""
     torch.cuda.synchronize(device)
     st = _stem_guard_state(device)
-    st['event'], st['tripped'] = None, False
+    st['event'], st['tripped'], st['calls'] = None, False, 0
     st['flag'].zero_()
     st['host'].zero_()
 
@@ -406,7 +409,9 @@ def stem_conv_pool(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, split: 
         check(lib().lsq_stem_conv_pool(x.data_ptr(), n, h, wd, w.data_ptr(), bias.data_ptr(), int(split), y.data_ptr(),
                                        None if guard is None else guard['flag'].data_ptr(), stream_ptr(x.device)),
               'lsq_stem_conv_pool')
-        if guard is not None and guard['event'] is None:
+        if guard is not None:
+            guard['calls'] += 1
+        if guard is not None and guard['event'] is None and guard['calls'] % 16 == 1:
             guard['host'].copy_(guard['flag'], non_blocking=True)
             guard['event'] = torch.cuda.Event()
             guard['event'].record()
