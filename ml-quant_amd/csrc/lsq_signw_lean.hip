@@ -3,7 +3,7 @@
 // Same arithmetic as signw_conv_patch (lsq_signw_conv.hip): implicit GEMM over k = (tap, channel) on
 // v_mfma_f32_32x32x16_bf16 with x = hi + lo (two bf16 terms), fp32 accumulation -- bit-identical output
 // (tests/test_gpu_parity.py); replaces F.conv2d(x, w_q, ...) of quant/binary/binary_conv.py:165-173 for x_quant == 'fp'.
-// What differs is everything around the matrix core.  Measured on the general kernel (round 3, profiles/r03_signw_*):
+// What differs is everything around the matrix core.  Measured on the general kernel (round 3: s_memtime stamps and phase elimination):
 // ten VALU and nine scalar instructions per MFMA (weight-bit expansion, per-item branches, address arithmetic), and
 // -- the larger part -- a vector-memory pipe saturated by 4-byte accesses: every dword load / store costs a full
 // 16-cycle address pass, so the fp32 patch of one 16-channel chunk (32 KB) took 2000 cycles of the CU's load path and
