@@ -472,6 +472,19 @@ def main():
             cfg['cifar100_ls1_kd_b100'] = config_leg('cifar', m, xc, 100, 5, 'ResNet-18 CIFAR-100 cifar100_ls1_kd (ls-1 weights and '
                                                      'activations, clamp 2), synthetic 3x32x32, batch 100 (yaml test_batch_size)', 192.6, graph=True)
             del m
+            # the headline network in the deployment configuration the reference's release notes motivate:
+            # moving-average activation scales (eval_only), i.e. NO scale solve at inference -- both planes in one read
+            arch_ma = imagenet_arch('ls-2', 3)
+            arch_ma.update(moving_average_mode='eval_only', moving_average_momentum=0.0)
+            m = build_model(arch_ma, device)
+            m.train()
+            with torch.no_grad():
+                m(x[:4])                              # one calibration step (torch formulation): the scale buffers take the batch's values
+            m.eval()
+            cfg['imagenet_ls1w_ls2a_moving_average_b256'] = config_leg(
+                'ma', m, x, 40, 5, 'ResNet-18 ImageNet ls-1 weight / ls-2 activation with moving-average (eval_only) activation scales: '
+                'the quantizer only packs, synthetic 3x224x224, batch 256')
+            del m
             m = build_lenet(device)
             xm = torch.randn(64, 1, 28, 28, generator=torch.Generator().manual_seed(0)).to(device)
             cfg['mnist_lenet_ls1w_fpa_b64'] = config_leg('lenet', m, xm, 200, 5, 'LeNet-5 mnist_ls1_weight_fp_activation, synthetic '

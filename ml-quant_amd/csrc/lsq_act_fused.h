@@ -20,6 +20,7 @@ struct FusedArgs {
   int N;
   int ternary;
   int debug;                // developer / test switches: 1 every flagged bin through the block path, 2 a 2048-key list
+  const float* forced;      // [2][N] scales given by the caller (moving-average inference): no solve, planes only
 };
 
 constexpr int kFusedNotEligible = 1;   // the shape is left to the streaming three-kernel path

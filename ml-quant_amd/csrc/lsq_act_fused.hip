@@ -1011,23 +1011,24 @@ static __device__ __forceinline__ void push_bits(unsigned& w0, unsigned& w1, flo
 
 // full 64-channel groups: every channel index is a compile-time constant
 template <int VEC, bool AFFINE>
-static __device__ __forceinline__ double pass2_full(const FusedArgs& a, FusedLds* lds, const float* __restrict__ xrow, float v1,
-                                                    unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1) {
-  const int tid = threadIdx.x;
+static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const float* bn_s, const float* bn_t,
+                                                    const float* __restrict__ xrow, float v1,
+                                                    unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1,
+                                                    int item0, int item_step) {
   const int HW = a.H * a.W;
   const int PV = (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   const float alpha = a.alpha >= 0.f ? a.alpha : INFINITY;
   double acc = 0.0;
-  for (int item = tid; item < items; item += kThreads) {
+  for (int item = item0; item < items; item += item_step) {
     const int j = item / PV;
     const int p = (item - j * PV) * VEC;
     const int grp = j / a.Gg;
     const int jj = j - grp * a.Gg;
     const int c0 = grp * a.cg + jj * 64;
     const float* __restrict__ src = xrow + (long long)c0 * HW + p;
-    const float* __restrict__ bs = lds->bn_s + c0;
-    const float* __restrict__ bt = lds->bn_t + c0;
+    const float* __restrict__ bs = bn_s + c0;      // (LDS copies of the folded batch norm)
+    const float* __restrict__ bt = bn_t + c0;
     unsigned w0[VEC][2], w1[VEC][2];
     float facc[VEC];
 #pragma unroll
@@ -1099,14 +1100,14 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, FusedLds
 // any channel count (groups that are not multiples of 64: LeNet's 20 channels, grouped convolutions)
 template <int VEC>
 static __device__ __forceinline__ double pass2_any(const FusedArgs& a, const float* __restrict__ xrow, float v1,
-                                                   unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1) {
-  const int tid = threadIdx.x;
+                                                   unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1,
+                                                   int item0, int item_step) {
   const int HW = a.H * a.W;
   const int PV = (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   const bool affine = a.pre_scale != nullptr;
   double acc = 0.0;
-  for (int item = tid; item < items; item += kThreads) {
+  for (int item = item0; item < items; item += item_step) {
     const int j = item / PV;
     const int p = (item - j * PV) * VEC;
     const int grp = j / a.Gg;
@@ -1288,9 +1289,10 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
   double acc;
   if ((a.cg & 63) == 0 && a.C <= kBnCap) {
-    acc = affine ? pass2_full<VEC, true>(a, lds, xrow, v1, prow0, prow1) : pass2_full<VEC, false>(a, lds, xrow, v1, prow0, prow1);
+    acc = affine ? pass2_full<VEC, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads)
+                 : pass2_full<VEC, false>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads);
   } else {
-    acc = pass2_any<VEC>(a, xrow, v1, prow0, prow1);
+    acc = pass2_any<VEC>(a, xrow, v1, prow0, prow1, tid, kThreads);
   }
   const double tot = block_sum(acc, lds);
   FMARK(10);
@@ -1306,6 +1308,56 @@ __global__ __launch_bounds__(T) void aq_fused_kernel(FusedArgs a) {
   using I = Impl<T>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(typename I::FusedLds)];
   I::template run<U, VEC>(a, reinterpret_cast<typename I::FusedLds*>(smem));
+}
+
+// Scales given by the caller (moving-average inference modes, activation_quantization.py:90-98: the deployment
+// configuration -- no solve at inference): pass 2 alone, ONE read of the input for both planes (the streaming
+// sweeps read it once per plane).  No row reduction is left, so the grid is decoupled from N: blockIdx.y = row,
+// blockIdx.x = one of `parts` interleaved shares of the row's items.
+template <int T, int VEC>
+__global__ __launch_bounds__(T) void aq_forced_kernel(FusedArgs a) {
+  using I = Impl<T>;
+  __shared__ float bn_s[kBnCap], bn_t[kBnCap];
+  const int tid = threadIdx.x, row = blockIdx.y;
+  const bool stage = a.pre_scale != nullptr && a.C <= kBnCap;
+  if (stage) {
+    for (int i = tid; i < a.C; i += T) {
+      bn_s[i] = a.pre_scale[i];
+      bn_t[i] = a.pre_shift[i];
+    }
+    __syncthreads();
+  }
+  const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
+  unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
+  unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
+  const float v1 = a.forced[row];
+  const int item0 = (int)blockIdx.x * T + tid, step = (int)gridDim.x * T;
+  if ((a.cg & 63) == 0 && a.C <= kBnCap) {
+    if (a.pre_scale != nullptr) I::template pass2_full<VEC, true>(a, bn_s, bn_t, xrow, v1, prow0, prow1, item0, step);
+    else I::template pass2_full<VEC, false>(a, bn_s, bn_t, xrow, v1, prow0, prow1, item0, step);
+  } else {
+    I::template pass2_any<VEC>(a, xrow, v1, prow0, prow1, item0, step);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    a.scales[row] = v1;
+    a.scales[(long long)a.N + row] = a.forced[(long long)a.N + row];
+  }
+}
+
+template <int T>
+int launch_forced(const FusedArgs& a, int vec, hipStream_t st) {
+  const long long HW = (long long)a.H * a.W;
+  const long long items = (long long)a.Gt * ((HW + vec - 1) / vec);
+  // shares per row: every lane an item if there are that many, about four workgroups per CU over the batch
+  long long parts = (items + T - 1) / T;
+  const long long want = (1024 + a.N - 1) / a.N;
+  if (parts > want) parts = want;
+  if (parts < 1) parts = 1;
+  const dim3 grid((unsigned)parts, (unsigned)a.N);
+  if (vec == 4) hipLaunchKernelGGL((aq_forced_kernel<T, 4>), grid, dim3(T), 0, st, a);
+  else if (vec == 2) hipLaunchKernelGGL((aq_forced_kernel<T, 2>), grid, dim3(T), 0, st, a);
+  else hipLaunchKernelGGL((aq_forced_kernel<T, 1>), grid, dim3(T), 0, st, a);
+  return (int)hipGetLastError();
 }
 
 template <int T, int U>
@@ -1337,6 +1389,11 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
     if ((v == 4 || v == 2 || v == 1) && HW % v == 0) vec = v;
   }
 #endif
+  if (a.forced) {
+    if (a.N > 65535) return kFusedNotEligible;       // (grid y)
+    // no rounds to balance here: the widest loads the image allows
+    return launch_forced<T>(a, HW % 4 == 0 ? 4 : (HW % 2 == 0 ? 2 : 1), st);
+  }
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
   if (need <= 5) return launch<T, 5>(a, vec, st);

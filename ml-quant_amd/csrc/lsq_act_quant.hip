@@ -1766,8 +1766,10 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   const int HW = g->H * g->W;
   const bool al16 = ((uintptr_t)x % 16) == 0, al8 = ((uintptr_t)x % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
-  if (solver && skip == 3 && !g_force_streaming.load(std::memory_order_relaxed)) {
-    // single launch with the sub-sample resident on chip (lsq_act_fused.hip) when the row fits
+  const bool forced2 = forced && (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST);
+  if (((solver && skip == 3) || forced2) && !g_force_streaming.load(std::memory_order_relaxed)) {
+    // single launch with the sub-sample resident on chip (lsq_act_fused.hip) when the row fits; with the caller's
+    // scales (moving-average inference) both planes in one read of the input
     FusedArgs f = {};
     f.x = x; f.row_elems = a.row_elems;
     f.C = a.C; f.H = a.H; f.W = a.W; f.cg = a.cg; f.Gg = a.Gg; f.Gt = a.Gt; f.Hp = a.Hp; f.Wp = a.Wp;
@@ -1775,6 +1777,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     f.alpha = clamp_alpha; f.pre_scale = pre_scale; f.pre_shift = pre_shift;
     f.planes = a.planes; f.plane_words = a.plane_words; f.row_words = a.row_words;
     f.scales = scales; f.N = a.N; f.ternary = a.ternary; f.debug = g_fused_debug.load(std::memory_order_relaxed);
+    f.forced = forced2 ? forced : nullptr;
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
   }

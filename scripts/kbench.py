@@ -46,6 +46,8 @@ def main():
                     help='input distribution: N(0,1); relu(N(0,1)); per-channel affine of relu (what a BN after a ReLU feeds)')
     ap.add_argument('--fold', action='store_true', help='fold a per-channel scale / shift into the quantizer read (as the network does)')
     ap.add_argument('--xnor-popcount', action='store_true', help='every XNOR convolution through the popcount kernel')
+    ap.add_argument('--streaming', action='store_true', help='quantizer through the streaming sweeps (test hook lsq_debug_force_streaming)')
+    ap.add_argument('--forced', action='store_true', help='quantizer with the caller\'s scales (moving-average inference): no solve')
     args = ap.parse_args()
     _hip.xnor_impl(args.xnor_popcount)
     dev = 'cuda:0'
@@ -71,7 +73,9 @@ def main():
         pre = None
         if args.fold:
             pre = ((0.5 + torch.rand(c, device=dev)).contiguous(), (torch.randn(c, device=dev) * 0.3).contiguous())
-        tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales, pre=pre), args.iters)
+        forced = (torch.rand((k, n), device=dev) + 0.5).contiguous() if args.forced else None
+        with _hip.debug_switches(force_streaming=args.streaming):
+            tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales, pre=pre, forced=forced), args.iters)
         tc = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), args.iters)
         wprep = _hip.signw_prepare_weight(wbits, 1, g)      # (the prepared weight image: the fast path, as the modules use it)
         tf = timeit(lambda: _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y, wprep=wprep), args.iters)

@@ -314,6 +314,42 @@ def test_stem_fp16_split_reports_out_of_range_operands_and_the_model_falls_back(
         hip.stem_overflow_reset(DEV)
 
 
+# ---------------------------------------------------------------------------------------------- caller's scales: one read
+@pytest.mark.parametrize('scheme', [2, 3])
+def test_forced_scales_one_read_kernel_equals_the_streaming_sweeps(scheme):
+    """Moving-average inference (activation_quantization.py:90-98): with the caller's scales lsq_act_quant packs both
+    planes of ls-2 / ls-T in ONE read of the input (aq_forced_kernel, grid decoupled from the batch); the streaming
+    sweeps (one read per plane) stay behind lsq_debug_force_streaming.  Same planes bit for bit, scales passed through:
+    the seven ResNet shapes at small batch, a single sample, grouped / odd-sized / LeNet-like rows (the general item
+    loop), with and without the folded batch norm."""
+    hip = _hip()
+    cases = [(3, 64, 56, 56, 1), (2, 128, 28, 28, 1), (5, 256, 14, 14, 1), (2, 512, 7, 7, 1), (1, 64, 8, 8, 1), (3, 128, 6, 10, 2),
+             (2, 20, 12, 12, 1), (7, 64, 4, 4, 1), (300, 64, 4, 4, 1)]
+    for ci, (n, c, h, w, groups) in enumerate(cases):
+        for fold in (False, True):
+            x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(50 + ci)).to(DEV) * 1.3
+            forced = (torch.rand(2, n, generator=torch.Generator().manual_seed(90 + ci)) * 0.8 + 0.4).to(DEV)
+            if scheme == 3:
+                forced[1] = forced[0]
+            pre = None
+            if fold:
+                g = torch.Generator().manual_seed(70 + ci)
+                pre = ((torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV))
+            geom = hip.make_geom(n, c, h, w, 64, 3, 3, (1, 1), (1, 1), (1, 1), groups)
+            words = hip.act_plane_words(geom)
+            out = []
+            for streaming in (False, True):
+                planes = torch.zeros((2 * words,), dtype=torch.int64, device=DEV)
+                scales = torch.full((2, n), -1.0, device=DEV)
+                with hip.debug_switches(force_streaming=streaming):
+                    hip.act_quant(x, geom, scheme, 2, 3, 2.5, planes, scales, forced, pre=pre)
+                torch.cuda.synchronize()
+                out.append((planes.clone(), scales.clone()))
+            assert torch.equal(out[0][0], out[1][0]), (scheme, n, c, h, w, groups, fold)
+            assert torch.equal(out[0][1], forced) and torch.equal(out[1][1], forced)
+            assert int((out[0][0] != 0).sum()) > 0
+
+
 # ---------------------------------------------------------------------------------------------- HIP-graph replay
 def test_graph_replay_equals_eager_forward():
     """quant/common/graph_replay.py: a CIFAR-sized quantized ResNet captured in a HIP graph returns the eager forward's
