@@ -1344,6 +1344,98 @@ __global__ __launch_bounds__(T) void aq_forced_kernel(FusedArgs a) {
   }
 }
 
+// Greedy 2-bit scheme (gf-2, quantization.py:118-148): v1 = mean |x| of the row, then exactly the planes and the second
+// scale of the least-squares 2-bit scheme.  One launch, one workgroup per row: a flat coalesced sweep sums |x| (fp64 per
+// lane), pass 2 follows from the same workgroup -- its read is served by the L2 / Infinity Cache the first one filled.
+// (The streaming path takes two launches of 1024-thread sweeps.)
+template <int T, int VEC>
+__global__ __launch_bounds__(T) void aq_greedy2_kernel(FusedArgs a) {
+  using I = Impl<T>;
+  __shared__ float bn_s[kBnCap], bn_t[kBnCap];
+  __shared__ double red[T / 64];
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const bool affine = a.pre_scale != nullptr;
+  if (affine && a.C <= kBnCap) {
+    for (int i = tid; i < a.C; i += T) {
+      bn_s[i] = a.pre_scale[i];
+      bn_t[i] = a.pre_shift[i];
+    }
+  }
+  __syncthreads();
+  const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
+  const long long M = a.row_elems;
+  const int HW = a.H * a.W;
+  auto block_total = [&](double v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < T / 64; ++w) t += red[w];
+    return t;
+  };
+  // sum |clamp(bn(x))| over the whole row, flat and coalesced
+  double acc = 0.0;
+  {
+    const float4* __restrict__ row4 = reinterpret_cast<const float4*>(xrow);
+    const unsigned nvec = (unsigned)(M / 4);
+    const float hinv = 1.0f / (float)HW;
+    constexpr int B = 8;                          // independent loads in flight per lane
+    for (unsigned i0 = (unsigned)tid; i0 < nvec; i0 += B * T) {
+      float4 v[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) v[b] = row4[min(i0 + (unsigned)b * T, nvec - 1u)];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const unsigned i = i0 + (unsigned)b * T;
+        if (i < nvec) {
+          float xs[4] = {v[b].x, v[b].y, v[b].z, v[b].w};
+          if (affine) {
+            const unsigned e = 4u * i;
+            unsigned c = (unsigned)((float)e * hinv);
+            if ((c + 1u) * (unsigned)HW <= e) ++c;
+            if (c * (unsigned)HW > e) --c;
+            const unsigned r = e - c * (unsigned)HW;            // position inside the channel; HW >= 4: at most one boundary
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const unsigned ck = min(c + (r + (unsigned)k >= (unsigned)HW ? 1u : 0u), (unsigned)a.C - 1u);
+              const float sc = a.C <= kBnCap ? bn_s[ck] : a.pre_scale[ck];
+              const float sh = a.C <= kBnCap ? bn_t[ck] : a.pre_shift[ck];
+              xs[k] = fmaf(xs[k], sc, sh);
+            }
+          }
+          const float x0 = clamp_sym(xs[0], a.alpha), x1 = clamp_sym(xs[1], a.alpha);
+          const float x2 = clamp_sym(xs[2], a.alpha), x3 = clamp_sym(xs[3], a.alpha);
+          acc += (double)((fabsf(x0) + fabsf(x1)) + (fabsf(x2) + fabsf(x3)));
+        }
+      }
+    }
+  }
+  const float v1 = (float)(block_total(acc) / (double)M);
+  unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
+  unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
+  double acc2;
+  if ((a.cg & 63) == 0 && a.C <= kBnCap) {
+    acc2 = affine ? I::template pass2_full<VEC, true>(a, bn_s, bn_t, xrow, v1, prow0, prow1, tid, T)
+                  : I::template pass2_full<VEC, false>(a, bn_s, bn_t, xrow, v1, prow0, prow1, tid, T);
+  } else {
+    acc2 = I::template pass2_any<VEC>(a, xrow, v1, prow0, prow1, tid, T);
+  }
+  const double tot2 = block_total(acc2);
+  if (tid == 0) {
+    a.scales[row] = v1;
+    a.scales[(long long)a.N + row] = (float)(tot2 / (double)M);
+  }
+}
+
+template <int T>
+int launch_greedy(const FusedArgs& a, int vec, hipStream_t st) {
+  if (vec == 4) hipLaunchKernelGGL((aq_greedy2_kernel<T, 4>), dim3(a.N), dim3(T), 0, st, a);
+  else if (vec == 2) hipLaunchKernelGGL((aq_greedy2_kernel<T, 2>), dim3(a.N), dim3(T), 0, st, a);
+  else hipLaunchKernelGGL((aq_greedy2_kernel<T, 1>), dim3(a.N), dim3(T), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 template <int T>
 int launch_forced(const FusedArgs& a, int vec, hipStream_t st) {
   const long long HW = (long long)a.H * a.W;
@@ -1394,6 +1486,7 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
     // no rounds to balance here: the widest loads the image allows
     return launch_forced<T>(a, HW % 4 == 0 ? 4 : (HW % 2 == 0 ? 2 : 1), st);
   }
+  if (a.greedy) return launch_greedy<T>(a, vec, st);
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
   if (need <= 5) return launch<T, 5>(a, vec, st);

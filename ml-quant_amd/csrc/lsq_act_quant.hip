@@ -1766,8 +1766,10 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   const int HW = g->H * g->W;
   const bool al16 = ((uintptr_t)x % 16) == 0, al8 = ((uintptr_t)x % 8) == 0;
   hipStream_t st = (hipStream_t)stream;
-  const bool forced2 = forced && (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST);
-  if (((solver && skip == 3) || forced2) && !g_force_streaming.load(std::memory_order_relaxed)) {
+  // (gf-2 has the planes of ls-2: with given scales the same kernel serves it; without, v1 = mean |x| replaces the solve)
+  const bool gf2 = scheme == LSQ_SCHEME_GF && k == 2;
+  const bool forced2 = forced && (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST || gf2);
+  if (((solver && skip == 3) || forced2 || gf2) && !g_force_streaming.load(std::memory_order_relaxed)) {
     // single launch with the sub-sample resident on chip (lsq_act_fused.hip) when the row fits; with the caller's
     // scales (moving-average inference) both planes in one read of the input
     FusedArgs f = {};
@@ -1778,6 +1780,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     f.planes = a.planes; f.plane_words = a.plane_words; f.row_words = a.row_words;
     f.scales = scales; f.N = a.N; f.ternary = a.ternary; f.debug = g_fused_debug.load(std::memory_order_relaxed);
     f.forced = forced2 ? forced : nullptr;
+    f.greedy = (gf2 && !forced) ? 1 : 0;
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
   }

@@ -350,6 +350,56 @@ def test_forced_scales_one_read_kernel_equals_the_streaming_sweeps(scheme):
             assert int((out[0][0] != 0).sum()) > 0
 
 
+def test_greedy_two_bit_single_launch_kernel():
+    """gf-2 (quantization.py:118-148, k = 2) in one launch (aq_greedy2_kernel): v1 = mean |x|, then the planes and the
+    second scale of the 2-bit least-squares scheme.  Scales against an fp64 evaluation (1e-6), planes bit-equal to the
+    oracle's planes for the kernel's own scales, on the ResNet shapes (7 x 7 with a folded batch norm: vectors that
+    straddle two channels), grouped and LeNet-like rows; and against the two streaming sweeps."""
+    hip = _hip()
+    cases = [(3, 64, 56, 56, 1), (2, 128, 28, 28, 1), (3, 256, 14, 14, 1), (4, 512, 7, 7, 1), (2, 128, 6, 10, 2), (2, 20, 12, 12, 1), (5, 64, 4, 4, 1)]
+    for ci, (n, c, h, w, groups) in enumerate(cases):
+        for fold in (False, True):
+            x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(150 + ci)).to(DEV) * 1.3
+            pre = None
+            xin = x
+            if fold:
+                g = torch.Generator().manual_seed(170 + ci)
+                pre = ((torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV))
+                xin = torch.addcmul(pre[1].view(1, -1, 1, 1), x, pre[0].view(1, -1, 1, 1))      # one fma per element, as the kernel
+            xc = xin.clamp(-2.5, 2.5).cpu()
+            geom = hip.make_geom(n, c, h, w, 64, 3, 3, (1, 1), (1, 1), (1, 1), groups)
+            words = hip.act_plane_words(geom)
+            res = []
+            for streaming in (False, True):
+                planes = torch.zeros((2 * words,), dtype=torch.int64, device=DEV)
+                scales = torch.full((2, n), -1.0, device=DEV)
+                with hip.debug_switches(force_streaming=streaming):
+                    hip.act_quant(x, geom, 4, 2, 3, 2.5, planes, scales, None, pre=pre)
+                torch.cuda.synchronize()
+                res.append((planes.cpu(), scales.cpu()))
+            planes, scales = res[0]
+            flat = xc.double().reshape(n, -1)
+            want1 = flat.abs().mean(dim=1)
+            want2 = (flat - scales[0].double().view(-1, 1) * P.pm1(flat)).abs().mean(dim=1)
+            assert torch.allclose(scales[0].double(), want1, rtol=1e-6, atol=0), (ci, fold)
+            assert torch.allclose(scales[1].double(), want2, rtol=1e-6, atol=0), (ci, fold)
+            assert torch.allclose(res[1][1], scales, rtol=1e-6, atol=0)
+            cg = c // groups
+            gt = groups * ((cg + 63) // 64)
+            got = planes.numpy().view(np.uint64).reshape(2, n, gt, h + 2, w + 2)
+            b1 = P.pm1(xc) > 0
+            b2 = P.pm1(xc - scales[0].view(-1, 1, 1, 1) * P.pm1(xc)) > 0
+            for q, b in enumerate((b1, b2)):
+                bits = b.reshape(n, groups, cg, h, w).numpy()
+                for gi in range(groups):
+                    for j in range((cg + 63) // 64):
+                        chunk = bits[:, gi, 64 * j:64 * (j + 1)]
+                        word = np.zeros((n, h, w), dtype=np.uint64)
+                        for k in range(chunk.shape[1]):
+                            word |= chunk[:, k].astype(np.uint64) << np.uint64(k)
+                        assert np.array_equal(got[q][:, gi * ((cg + 63) // 64) + j, 1:-1, 1:-1], word), (ci, fold, q, gi, j)
+
+
 # ---------------------------------------------------------------------------------------------- HIP-graph replay
 def test_graph_replay_equals_eager_forward():
     """quant/common/graph_replay.py: a CIFAR-sized quantized ResNet captured in a HIP graph returns the eager forward's
