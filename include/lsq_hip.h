@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 6
+#define LSQ_ABI_VERSION 7
 
 /* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
 #define LSQ_ACT_NONE 0
@@ -102,7 +102,11 @@ int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
  *                activation_quantization.py:90-98)
  *   planes       out, [k] activation planes laid out as described above (halo pre-zeroed)
  *   scales       out, [k][N] fp32: v1..vk per sample (LST: row 1 repeats v1)
- *   workspace    lsq_solver_workspace_bytes(N) bytes, 8-byte aligned (LS2 / LST without forced scales)
+ *   workspace    LS2 / LST without forced scales: lsq_solver_workspace_bytes(N) bytes, 8-byte aligned (required).
+ *                LS1 / GF without forced scales: NULL, or lsq_sweep_workspace_bytes(N) bytes, 8-byte aligned, ZEROED
+ *                by the caller before its first use (every call leaves it zeroed again; one buffer per stream):
+ *                with it a row may be shared by several workgroups when the batch alone would leave CUs idle --
+ *                same planes, the scale is the same fixed-order sum either way.
  */
 int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
                   float clamp_alpha, const float* pre_scale, const float* pre_shift,
@@ -112,6 +116,9 @@ int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int
 /* Bytes of scratch the LS2 / LST scale solve needs for `rows` rows (slot records handed from the
  * histogram sweep to the solve kernel).  Not needed (may be NULL / 0) for LS1, GF or forced scales. */
 int64_t lsq_solver_workspace_bytes(int64_t rows);
+
+/* Bytes of the optional row workspace of the LS1 / GF sweeps (partial sums and an arrival counter per row). */
+int64_t lsq_sweep_workspace_bytes(int64_t rows);
 
 /*
  * Stand-alone optimal-v1 solve on a dense [R][M] fp32 matrix (rows need not be activations):

@@ -81,8 +81,12 @@ struct Args {
   int ternary;
   int write_scale;          // sweep kernels: store mean|residual| as scale q
   int csplit_log2;          // sweep kernels: 2^csplit_log2 lanes share one (64 channels x VEC pixels) item
+  int parts;                // sweep kernels without histogram: workgroups that share one row (grid = parts x N)
   unsigned char* ws;        // workspace (kWsRow bytes per row)
+  unsigned char* rws;       // row-split sweeps: kSplitRow bytes per row (partial sums + arrival counter), zero between launches
 };
+constexpr int kMaxParts = 8;
+constexpr int kSplitRow = 8 * (kMaxParts + 1);           // bytes: kMaxParts fp64 partial sums + a 64-bit slot for the counter
 
 // one flagged sub-bin of a slot, queued by the wave that scanned the slot and resolved by whichever wave is
 // free: the 16 waves then share the expensive part instead of one wave walking all sub-bins of its slot
@@ -320,7 +324,10 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
   const int csl = SPLIT ? a.csplit_log2 : 0, cs = 1 << csl;
   const int part = SPLIT ? (int)(threadIdx.x & (cs - 1)) : 0;
   const int cper = 64 >> csl;
-  for (int item = threadIdx.x >> csl; item < items; item += kThreads >> csl) {
+  // (row-split sweeps: the row's a.parts workgroups form one pool of parts * kThreads lanes; the lanes that share an item
+  //  are consecutive lanes of one wave either way)
+  const int wparts = a.parts > 1 ? a.parts : 1, wpart = a.parts > 1 ? (int)blockIdx.x : 0;
+  for (int item = (wpart * kThreads + (int)threadIdx.x) >> csl; item < items; item += (wparts * kThreads) >> csl) {
     const int j = item / PV;
     const int p = (item - j * PV) * VEC;
     const int grp = j / a.Gg;
@@ -1538,7 +1545,7 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   using L = typename std::conditional<HIST, SweepLds, SmallLds>::type;
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(L)];
   L* lds = reinterpret_cast<L*>(smem);
-  const int row = blockIdx.x;
+  const int row = a.parts > 1 ? (int)blockIdx.y : (int)blockIdx.x;
   const int tid = threadIdx.x;
 #ifdef LSQ_PHASE_CLOCKS
   if (tid == 0 && row < 1024) g_sweep_times[HIST ? 0 : 1][row][0] = (long long)wall_clock64();
@@ -1580,7 +1587,26 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
     }
   }
   LSQ_MARK(7);
-  if (a.write_scale && tid == 0) a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);
+  if (a.write_scale && tid == 0) {
+    if (!HIST && a.parts > 1) {
+      // the row's workgroups leave their partial sums and take a ticket; the last one adds them up in part order
+      // (the same sum whichever workgroup comes last) and leaves the counter at zero for the next launch
+      double* partial = reinterpret_cast<double*>(a.rws + (long long)row * kSplitRow);
+      unsigned* counter = reinterpret_cast<unsigned*>(partial + kMaxParts);
+      __hip_atomic_store(&partial[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == (unsigned)a.parts - 1u) {
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        double t = 0.0;
+        for (int p = 0; p < a.parts; ++p) t += __hip_atomic_load(&partial[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.scales[(long long)q * a.N + row] = (float)(t / (double)a.row_elems);
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);
+    }
+  }
   if constexpr (HIST) {
     const unsigned n_sub = (unsigned)((a.row_elems + a.skip - 1) / a.skip);
     LSQ_MARK(8);
@@ -1666,7 +1692,8 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
 
 template <int VEC>
 int launch_sweep(const Args& a, int q, bool hist, hipStream_t st) {
-  const dim3 grid(a.N), block(kThreads);
+  const dim3 grid = (!hist && a.parts > 1) ? dim3((unsigned)a.parts, (unsigned)a.N) : dim3((unsigned)a.N);
+  const dim3 block(kThreads);
   if (hist) hipLaunchKernelGGL((aq_sweep_kernel<VEC, true, 0>), grid, block, 0, st, a, q);
   else if (q == 0) hipLaunchKernelGGL((aq_sweep_kernel<VEC, false, 0>), grid, block, 0, st, a, q);
   else if (q == 1) hipLaunchKernelGGL((aq_sweep_kernel<VEC, false, 1>), grid, block, 0, st, a, q);
@@ -1681,13 +1708,34 @@ int run(Args a, hipStream_t st) {
   // batch of loads (32 / VEC channels)
   if (!a.flat) {
     const long long items = (long long)a.Gt * ((a.H * a.W + VEC - 1) / VEC);
+    // Workgroups per row (row-split sweeps): when the batch alone leaves CUs idle (small batches), up to kMaxParts
+    // workgroups share a row, at most one workgroup per CU over the batch.  Needs the caller's zeroed row
+    // workspace and a scale to reduce (the plain sweeps of ls-1 / gf-k; not the histogram sweep, not forced scales).
+    // (measured, scripts/sweep_split.py: up to 32 rows every shape gains -- 56 x 56 x 64: 30 -> 11 us --; from 33 to 128
+    //  rows only rows of half a megabyte and more do, two workgroups each; beyond, one workgroup per row fills the chip)
+    long long parts = 1;
+    if (a.rws && !a.forced) {
+      if (a.N <= 32) parts = 256 / (a.N > 0 ? a.N : 1);
+      else if (a.N <= 128 && a.row_elems * 4 >= (512ll << 10)) parts = 2;
+      if (parts > kMaxParts) parts = kMaxParts;
+      if (parts < 1) parts = 1;
+    }
+#ifdef LSQ_TUNE
+    if (const char* e = getenv("LSQ_SWEEP_PARTS")) { if (a.rws && !a.forced) parts = atoi(e) < 1 ? 1 : (atoi(e) > kMaxParts ? kMaxParts : atoi(e)); }
+#endif
+    // lanes per item: as many as leave no thread of the row's workgroups idle, as long as a lane's share of the 64
+    // channels is still a full batch of loads (32 / VEC channels)
     int csl = 0;
     if (VEC > 1)                                           // (one pixel per lane: 32 channels per batch, nothing to split)
-      while ((items << (csl + 1)) <= kThreads && (64 >> (csl + 1)) >= 32 / VEC) ++csl;
+      while ((items << (csl + 1)) <= parts * kThreads && (64 >> (csl + 1)) >= 32 / VEC) ++csl;
     a.csplit_log2 = csl;
 #ifdef LSQ_TUNE
     if (const char* e = getenv("LSQ_CSPLIT")) a.csplit_log2 = atoi(e) < csl ? atoi(e) : csl;
 #endif
+    // (no more workgroups than the row's lanes fill)
+    const long long fill = ((items << a.csplit_log2) + kThreads - 1) / kThreads;
+    if (parts > fill) parts = fill;
+    a.parts = (int)(parts < 1 ? 1 : parts);
   }
   const bool solver = (a.scheme == LSQ_SCHEME_LS2 || a.scheme == LSQ_SCHEME_LST) && !a.forced;
   if (a.forced) {
@@ -1724,6 +1772,7 @@ extern "C" int64_t lsq_act_plane_words(const lsq_conv_geom* g) {
 }
 
 extern "C" int64_t lsq_solver_workspace_bytes(int64_t rows) { return rows > 0 ? rows * kWsRow : -1; }
+extern "C" int64_t lsq_sweep_workspace_bytes(int64_t rows) { return rows > 0 ? rows * kSplitRow : -1; }
 
 extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
                              float clamp_alpha, const float* pre_scale, const float* pre_shift,
@@ -1758,6 +1807,10 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   a.ternary = scheme == LSQ_SCHEME_LST;
   a.ws = (unsigned char*)workspace;
   const bool solver = (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && !forced;
+  // the plain sweeps (ls-1, gf-k) take an OPTIONAL workspace of lsq_sweep_workspace_bytes(N), zeroed once by the caller
+  // (every launch leaves it zeroed): with it a row may be shared by several workgroups (small batches)
+  a.rws = (!solver && !forced && workspace && (long long)workspace_bytes >= (long long)g->N * kSplitRow && ((uintptr_t)workspace % 8) == 0)
+              ? (unsigned char*)workspace : nullptr;
   if (solver) {
     if ((a.row_elems + skip - 1) / skip >= (1ll << 22)) return LSQ_E_TOO_LONG;
     if (!workspace) return LSQ_E_NULL;

@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -58,6 +58,8 @@ def _declare(lib):
     lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.lsq_solver_workspace_bytes.restype = i64
     lib.lsq_solver_workspace_bytes.argtypes = [i64]
+    lib.lsq_sweep_workspace_bytes.restype = i64
+    lib.lsq_sweep_workspace_bytes.argtypes = [i64]
     lib.lsq_solve_rows.restype = i32
     lib.lsq_solve_rows.argtypes = [vp, i64, i64, i32, i32, f32, vp, vp, vp, ctypes.c_size_t, vp]
     lib.lsq_pack_weight.restype = i32
@@ -210,12 +212,32 @@ def solver_workspace(rows: int, device) -> torch.Tensor:
     return buf
 
 
+_sweep_ws_cache = {}
+
+
+def sweep_workspace(rows: int, device) -> torch.Tensor:
+    """Row workspace of the ls-1 / gf-k sweeps (partial sums + arrival counters of rows shared by several workgroups):
+    zeroed here once, left zeroed by every call; cached per (device, stream) like the solver's."""
+    need = lib().lsq_sweep_workspace_bytes(rows)
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _sweep_ws_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros((need,), dtype=torch.uint8, device=device)
+        _sweep_ws_cache[key] = buf
+    return buf
+
+
 def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, alpha: float,
               planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None,
               pre: Optional[tuple] = None) -> None:
     """pre = (scale[C], shift[C]) folds an eval-mode batch norm into the read."""
     x = _f32c(x)
-    ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) and forced is None else None
+    ws = None
+    if forced is None:
+        ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) else sweep_workspace(geom.N, x.device)
     m = geom.C * geom.H * geom.W
     with _on(x), _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8), 0, f'C{geom.C}_H{geom.H}'):     # x read once + k bit planes written
         check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha),

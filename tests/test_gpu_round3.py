@@ -350,6 +350,39 @@ def test_forced_scales_one_read_kernel_equals_the_streaming_sweeps(scheme):
             assert int((out[0][0] != 0).sum()) > 0
 
 
+@pytest.mark.parametrize('scheme,k', [(1, 1), (4, 3)])
+def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
+    """ls-1 / gf-3 sweeps at small batch: with the (zeroed) row workspace a row is shared by up to eight workgroups
+    (grid decoupled from the batch), partial sums reduced by the last one to arrive in part order.  Same planes bit for
+    bit as without the workspace, scales equal to 1e-6 (fp64 sums grouped differently) and stable from call to call; the
+    workspace is left zeroed."""
+    hip = _hip()
+    for ci, (n, c, h, w) in enumerate([(2, 64, 56, 56), (5, 128, 28, 28), (1, 256, 14, 14), (100, 64, 32, 32), (3, 512, 7, 7)]):
+        x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(250 + ci)).to(DEV) * 1.2
+        geom = hip.make_geom(n, c, h, w, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+        words = hip.act_plane_words(geom)
+        lib = hip.lib()
+        import ctypes
+
+        def call(ws):
+            planes = torch.zeros((k * words,), dtype=torch.int64, device=DEV)
+            scales = torch.full((k, n), -1.0, device=DEV)
+            with torch.cuda.device(x.device):
+                e = lib.lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, 3, 2.0, None, None, None, planes.data_ptr(),
+                                      scales.data_ptr(), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                      hip.stream_ptr(x.device))
+            assert e == 0
+            torch.cuda.synchronize()
+            return planes.cpu(), scales.cpu()
+        ws = torch.zeros((lib.lsq_sweep_workspace_bytes(n),), dtype=torch.uint8, device=DEV)
+        p0, s0 = call(None)
+        p1, s1 = call(ws)
+        p2, s2 = call(ws)
+        assert torch.equal(p0, p1) and torch.equal(p1, p2)
+        assert torch.allclose(s0, s1, rtol=1e-6, atol=0) and torch.equal(s1, s2)
+        assert int(ws.sum()) == 0 or bool((ws.view(-1, 72)[:, 64:] == 0).all())      # counters back at zero
+
+
 def test_greedy_two_bit_single_launch_kernel():
     """gf-2 (quantization.py:118-148, k = 2) in one launch (aq_greedy2_kernel): v1 = mean |x|, then the planes and the
     second scale of the 2-bit least-squares scheme.  Scales against an fp64 evaluation (1e-6), planes bit-equal to the
