@@ -385,8 +385,8 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
 }
 
 template <int VEC, bool HIST, int QM, bool SPLIT, class L>
-__device__ __forceinline__ PassOut pack_pass(L* lds, const float* __restrict__ xrow, unsigned long long* __restrict__ prow, int q) {
-  const Args a = lds->args;              // registers (SGPRs): nothing below re-reads LDS for it
+__device__ __forceinline__ PassOut pack_pass(const Args& a, L* lds, const float* __restrict__ xrow, unsigned long long* __restrict__ prow, int q) {
+  // (a: the kernel's own argument block -- scalar registers; a copy staged through LDS cost a microsecond per launch)
   const Chain ch = load_chain(lds, q);
   const unsigned skip = (unsigned)a.skip;
   double acc = 0.0;
@@ -443,8 +443,7 @@ __device__ __forceinline__ PassOut pack_pass(L* lds, const float* __restrict__ x
 
 // flat rows (no planes): sum |residual| and optional histogram, coalesced
 template <bool HIST, int QM, class L>
-__device__ __forceinline__ PassOut flat_pass(L* lds, const float* __restrict__ xrow, int q) {
-  const Args a = lds->args;
+__device__ __forceinline__ PassOut flat_pass(const Args& a, L* lds, const float* __restrict__ xrow, int q) {
   const Chain ch = load_chain(lds, q);
   const long long M = a.row_elems;
   const unsigned skip = (unsigned)a.skip;
@@ -1554,19 +1553,21 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   if constexpr (HIST) {
     for (int i = tid; i < L1_BINS; i += kThreads) lds->hist1[i] = 0ull;
   }
-  if (tid == 0) lds->args = a;
+  if constexpr (HIST) {
+    if (tid == 0) lds->args = a;         // (the scan / slot routines below read it from here)
+  }
   if (tid < LSQ_MAX_PLANES) lds->sv[tid] = tid < q ? a.scales[(long long)tid * a.N + row] : 0.f;
   __syncthreads();
   if constexpr (HIST) LSQ_MARK(15);
   LSQ_MARK(0);
   PassOut po;
   if (a.flat) {
-    po = flat_pass<HIST, QM>(lds, xrow, q);
+    po = flat_pass<HIST, QM>(a, lds, xrow, q);
   } else {
     unsigned long long* prow = a.planes + (long long)q * a.plane_words + (long long)row * a.row_words;
     // (the split variant only where it is used: 8- and 16-byte loads; one pixel per lane has nothing to split)
-    if (VEC > 1 && a.csplit_log2 > 0) po = pack_pass<VEC, HIST, QM, (VEC > 1)>(lds, xrow, prow, q);
-    else po = pack_pass<VEC, HIST, QM, false>(lds, xrow, prow, q);
+    if (VEC > 1 && a.csplit_log2 > 0) po = pack_pass<VEC, HIST, QM, (VEC > 1)>(a, lds, xrow, prow, q);
+    else po = pack_pass<VEC, HIST, QM, false>(a, lds, xrow, prow, q);
   }
   LSQ_MARK(1);
   // row sum (and, for the histogram sweep, the smallest key) in one LDS exchange
