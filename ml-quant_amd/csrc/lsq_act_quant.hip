@@ -82,6 +82,8 @@ struct Args {
   int write_scale;          // sweep kernels: store mean|residual| as scale q
   int csplit_log2;          // sweep kernels: 2^csplit_log2 lanes share one (64 channels x VEC pixels) item
   int parts;                // sweep kernels without histogram: workgroups that share one row (grid = parts x N)
+  double qmagic;            // != 0: exact row sums -- every 8-channel group sum is rounded to a multiple of 2^e through
+                            // (g + qmagic) - qmagic, qmagic = 1.5 * 2^(52 + e), and fp64 adds such multiples exactly
   unsigned char* ws;        // workspace (kWsRow bytes per row)
   unsigned char* rws;       // row-split sweeps: kSplitRow bytes per row (partial sums + arrival counter), zero between launches
 };
@@ -384,7 +386,12 @@ __device__ __forceinline__ void sweep_row(const Args& a, const float* __restrict
   }
 }
 
-template <int VEC, bool HIST, int QM, bool SPLIT, class L>
+// EXACT (plain sweeps under a clamp): the row sum is the same NUMBER however the row's elements are dealt to lanes and
+// workgroups -- whatever the batch size, lane sharing or row split.  The fp32 sum of every group of 8 channels (fixed
+// membership and order) is rounded to a multiple of 2^e, e = ceil(log2 alpha) - 31 (|x| <= alpha: a relative step of
+// 2^-32 of a typical group sum), and multiples of 2^e below 2^(53 + e) -- 4 million elements at the clamp -- add without
+// rounding in fp64.
+template <int VEC, bool HIST, int QM, bool SPLIT, bool EXACT, class L>
 __device__ __forceinline__ PassOut pack_pass(const Args& a, L* lds, const float* __restrict__ xrow, unsigned long long* __restrict__ prow, int q) {
   // (a: the kernel's own argument block -- scalar registers; a copy staged through LDS cost a microsecond per launch)
   const Chain ch = load_chain(lds, q);
@@ -410,6 +417,12 @@ __device__ __forceinline__ PassOut pack_pass(const Args& a, L* lds, const float*
           chain_eval<QM>(ch, x[v], bit, ar);
           word[v] |= (unsigned long long)bit << cc;
           facc[v] += ar;
+          if constexpr (EXACT) {
+            if ((cc & 7) == 7) {                       // (cc counts from the lane's first channel, a multiple of 8)
+              acc += ((double)facc[v] + a.qmagic) - a.qmagic;
+              facc[v] = 0.f;
+            }
+          }
         }
         if constexpr (HIST) {
           emit_subsample<VEC>(x, rem, skip, [&](float xs) {
@@ -422,7 +435,8 @@ __device__ __forceinline__ PassOut pack_pass(const Args& a, L* lds, const float*
       [&](int j, int p, int cfirst, int cs) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          acc += (double)facc[v];
+          if constexpr (EXACT) acc += ((double)facc[v] + a.qmagic) - a.qmagic;    // (a last group of fewer than 8 channels; else 0)
+          else acc += (double)facc[v];
           unsigned long long wd = word[v];
           if constexpr (SPLIT) {
             wd <<= cfirst;                             // the lane's channels start at bit cfirst of the word
@@ -1566,8 +1580,13 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   } else {
     unsigned long long* prow = a.planes + (long long)q * a.plane_words + (long long)row * a.row_words;
     // (the split variant only where it is used: 8- and 16-byte loads; one pixel per lane has nothing to split)
-    if (VEC > 1 && a.csplit_log2 > 0) po = pack_pass<VEC, HIST, QM, (VEC > 1)>(a, lds, xrow, prow, q);
-    else po = pack_pass<VEC, HIST, QM, false>(a, lds, xrow, prow, q);
+    if (!HIST && a.qmagic != 0.0) {
+      if (VEC > 1 && a.csplit_log2 > 0) po = pack_pass<VEC, HIST, QM, (VEC > 1), !HIST>(a, lds, xrow, prow, q);
+      else po = pack_pass<VEC, HIST, QM, false, !HIST>(a, lds, xrow, prow, q);
+    } else {
+      if (VEC > 1 && a.csplit_log2 > 0) po = pack_pass<VEC, HIST, QM, (VEC > 1), false>(a, lds, xrow, prow, q);
+      else po = pack_pass<VEC, HIST, QM, false, false>(a, lds, xrow, prow, q);
+    }
   }
   LSQ_MARK(1);
   // row sum (and, for the histogram sweep, the smallest key) in one LDS exchange
@@ -1714,8 +1733,16 @@ int run(Args a, hipStream_t st) {
     // workspace and a scale to reduce (the plain sweeps of ls-1 / gf-k; not the histogram sweep, not forced scales).
     // (measured, scripts/sweep_split.py: up to 32 rows every shape gains -- 56 x 56 x 64: 30 -> 11 us --; from 33 to 128
     //  rows only rows of half a megabyte and more do, two workgroups each; beyond, one workgroup per row fills the chip)
+    // exact row sums under a clamp (the plain sweeps: not the solver's histogram sweep, not given scales)
+    const bool solver_scheme = a.scheme == LSQ_SCHEME_LS2 || a.scheme == LSQ_SCHEME_LST;
+    a.qmagic = 0.0;
+    if (!solver_scheme && !a.forced && a.alpha > 0.f && a.row_elems <= (1ll << 22)) {
+      int e2 = 0;
+      (void)frexpf(a.alpha, &e2);                          // alpha = m * 2^e2, 0.5 <= m < 1: 2^e2 >= alpha
+      a.qmagic = ldexp(1.5, 52 + e2 - 31);
+    }
     long long parts = 1;
-    if (a.rws && !a.forced) {
+    if (a.rws && !a.forced && a.qmagic != 0.0) {           // (shared rows change who adds what: only with exact sums)
       if (a.N <= 32) parts = 256 / (a.N > 0 ? a.N : 1);
       else if (a.N <= 128 && a.row_elems * 4 >= (512ll << 10)) parts = 2;
       if (parts > kMaxParts) parts = kMaxParts;
@@ -1728,7 +1755,7 @@ int run(Args a, hipStream_t st) {
     // channels is still a full batch of loads (32 / VEC channels)
     int csl = 0;
     if (VEC > 1)                                           // (one pixel per lane: 32 channels per batch, nothing to split)
-      while ((items << (csl + 1)) <= parts * kThreads && (64 >> (csl + 1)) >= 32 / VEC) ++csl;
+      while ((items << (csl + 1)) <= parts * kThreads && (64 >> (csl + 1)) >= 32 / VEC && (64 >> (csl + 1)) >= 8) ++csl;
     a.csplit_log2 = csl;
 #ifdef LSQ_TUNE
     if (const char* e = getenv("LSQ_CSPLIT")) a.csplit_log2 = atoi(e) < csl ? atoi(e) : csl;

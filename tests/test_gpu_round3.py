@@ -354,8 +354,8 @@ def test_forced_scales_one_read_kernel_equals_the_streaming_sweeps(scheme):
 def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
     """ls-1 / gf-3 sweeps at small batch: with the (zeroed) row workspace a row is shared by up to eight workgroups
     (grid decoupled from the batch), partial sums reduced by the last one to arrive in part order.  Same planes bit for
-    bit as without the workspace, scales equal to 1e-6 (fp64 sums grouped differently) and stable from call to call; the
-    workspace is left zeroed."""
+    bit as without the workspace and -- the row sums being exact under a clamp -- the same scales bit for bit, also for a
+    sample quantized alone; the workspace is left zeroed."""
     hip = _hip()
     for ci, (n, c, h, w) in enumerate([(2, 64, 56, 56), (5, 128, 28, 28), (1, 256, 14, 14), (100, 64, 32, 32), (3, 512, 7, 7)]):
         x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(250 + ci)).to(DEV) * 1.2
@@ -379,7 +379,19 @@ def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
         p1, s1 = call(ws)
         p2, s2 = call(ws)
         assert torch.equal(p0, p1) and torch.equal(p1, p2)
-        assert torch.allclose(s0, s1, rtol=1e-6, atol=0) and torch.equal(s1, s2)
+        # under a clamp the row sums are exact (multiples of 2^e added in fp64): the same scale bit for bit however the
+        # row was dealt to lanes and workgroups, and whatever the batch size
+        assert torch.equal(s0, s1) and torch.equal(s1, s2)
+        xs = x[:1].contiguous()
+        geom1 = hip.make_geom(1, c, h, w, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+        pl1 = torch.zeros((k * hip.act_plane_words(geom1),), dtype=torch.int64, device=DEV)
+        sc1 = torch.full((k, 1), -1.0, device=DEV)
+        ws1 = torch.zeros((lib.lsq_sweep_workspace_bytes(1),), dtype=torch.uint8, device=DEV)
+        with torch.cuda.device(x.device):
+            assert lib.lsq_act_quant(xs.data_ptr(), ctypes.byref(geom1), scheme, k, 3, 2.0, None, None, None, pl1.data_ptr(),
+                                     sc1.data_ptr(), ws1.data_ptr(), ws1.numel(), hip.stream_ptr(x.device)) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(sc1.cpu()[:, 0], s1[:, 0]), (ci, sc1, s1[:, 0])
         assert int(ws.sum()) == 0 or bool((ws.view(-1, 72)[:, 64:] == 0).all())      # counters back at zero
 
 
