@@ -105,6 +105,21 @@ def available() -> bool:
     return os.path.exists(_LIB_PATH)
 
 
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile; names and contents, sorted): counter profiles record
+    it when they are captured and bench.py attaches their figures only while it still matches -- a profile of older
+    kernels is reported as stale instead of silently priced against the current ones."""
+    import hashlib
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc')
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(src)):
+        if name.endswith(('.hip', '.h')) or name == 'Makefile':
+            h.update(name.encode() + b'\0')
+            with open(os.path.join(src, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def check(code: int, what: str) -> None:
     if code != 0:
         msg = lib().lsq_error_string(code).decode()

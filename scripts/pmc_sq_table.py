@@ -12,7 +12,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ml-quant_amd'))
+from quant import _hip  # noqa: E402
 
 
 def counters(directory, pattern):
@@ -46,7 +50,7 @@ def main():
             'active_inst_any_frac': c.get('SQ_ACTIVE_INST_ANY', 0.0) / wave, 'waves': c.get('SQ_WAVES', 0.0),
         })
     json.dump({'note': 'rocprofv3 --pmc passes (scripts/pmc_kernel.sh), one kernel on its own at batch 256; mfma_busy_frac = '
-                       'SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)', 'kernels': rows}, open(out_path, 'w'), indent=1)
+                       'SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)', 'csrc_sha256': _hip.source_fingerprint(), 'kernels': rows}, open(out_path, 'w'), indent=1)
     for r in rows:
         print(f"{r['entry']:18s} {r['shape']:12s} mfma busy {r['mfma_busy_frac']:.3f}  VALU/MFMA {r['valu_per_mfma']:.1f}  LDS conflicts "
               f"{r['lds_bank_conflict_frac']:.2f}  wait {r['wait_any_frac']:.2f}/{r['wait_inst_any_frac']:.2f}")

@@ -13,6 +13,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - "$dir" "$out" <<'PY'
 import collections, csv, glob, json, sys
+sys.path.insert(0, 'ml-quant_amd')
+from quant import _hip
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -29,7 +31,7 @@ for k, d in sorted(agg.items()):
               'hbm_read_MB_corrected': round(2 * f / 1024, 1), 'hbm_write_MB': round(w / 1024, 1)}
 json.dump({'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over '
                    'bench.py (ResNet-18 ls-1w/ls-2a, batch 256, 5 forwards); per-dispatch averages over all layers a kernel serves; grid = threads; FETCH_SIZE doubled per '
-                   'MI355X_MICROARCH.md (gfx950 counts 128-byte requests as 64 bytes)', 'kernels': res},
+                   'MI355X_MICROARCH.md (gfx950 counts 128-byte requests as 64 bytes)', 'csrc_sha256': _hip.source_fingerprint(), 'kernels': res},
           open(sys.argv[2], 'w'), indent=1)
 print(open(sys.argv[2]).read()[:3000])
 PY
