@@ -14,6 +14,8 @@
 #ifndef LSQ_HIP_DEBUG_H_
 #define LSQ_HIP_DEBUG_H_
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -24,6 +26,13 @@ int lsq_debug_xnor_impl(int popcount_only);
 int lsq_debug_force_streaming(int on);
 /* single-launch quantizer: 1 = every flagged bin through its block path, 2 = key list of 2048 entries (default 0) */
 int lsq_debug_fused_mode(int mode);
+
+/* device buffer of one int32 per row (sized by the caller for its largest batch; NULL = off, the default): every
+ * LS-2 / LS-T solve -- lsq_act_quant and lsq_solve_rows, single-launch and streaming path -- stores the SORTED POSITION of
+ * the candidate it chose (quant/binary/optimal.py:151: the argmin's element of the ascending sub-sample; the first
+ * position of its run when several keys are equal), n + 1 for the ternary extra candidate (optimal.py:86-118), -1 when
+ * the row has no candidate.  Lets the parity tests pin the candidate itself, not only its value.  Returns 0. */
+int lsq_debug_solver_trace(int32_t* device_rows);
 
 #ifdef __cplusplus
 }

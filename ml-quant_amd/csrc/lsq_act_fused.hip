@@ -102,7 +102,7 @@ struct FixedLds {
   unsigned wa[kWaves], wb[kWaves], wc[kWaves];
   double ws[kWaves];
   Best wbest[kWaves];
-  unsigned n_nodes, n_tasks, n_cells, arena_fill, blk_succ, n_slow, n_list, maxkey;
+  unsigned n_nodes, n_tasks, n_cells, arena_fill, blk_succ, n_slow, n_list, maxkey, best_order;
   unsigned long long slow_mask;
   double total;
   float v1;
@@ -906,7 +906,10 @@ static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
       o.value = __shfl_xor(r.value, d);
       if (better(o, r)) r = o;
     }
-    if (lane == 0) lds->v1 = r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
+    if (lane == 0) {
+      lds->v1 = r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
+      lds->best_order = r.order;
+    }
   }
   __syncthreads();
 }
@@ -1299,6 +1302,7 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   if (tid == 0) {
     a.scales[row] = v1;
     a.scales[(long long)a.N + row] = ternary ? v1 : (float)(tot / (double)M);
+    if (a.trace) a.trace[row] = (int)lds->best_order;
   }
 }
 };  // struct Impl

@@ -76,6 +76,7 @@ struct Args {
   long long row_words;      // words of one row of one plane
   float* scales;            // [k][N]
   int* status;              // flat mode: number of candidates per row
+  int* trace;               // test hook (lsq_debug_solver_trace): chosen sorted position per row, or null
   int N;
   int flat;                 // 1: dense [R][M] rows, no planes
   int ternary;
@@ -143,7 +144,7 @@ struct SolverLds {
   double ws[kWaves];
   Best wbest[kWaves];
   // scalars
-  unsigned n_sub, n_cand, n_slow, blk_succ;
+  unsigned n_sub, n_cand, n_slow, blk_succ, best_order;
   unsigned task_cnt[3];                           // tasks queued in the current / next / after-next round
   unsigned dbg_slow, dbg_gathered, dbg_rowpass;   // diagnostics written back to the row header
   unsigned rg_lo[4], rg_len[4], rg_first[4], rg_succbin[4], rg_last[4], n_rg;   // runs of consecutive flagged bins
@@ -1547,6 +1548,7 @@ __device__ __forceinline__ float solve_v1(SolverLds* lds, const float* __restric
     o.value = __shfl_xor(r.value, d);
     if (better(o, r)) r = o;
   }
+  if (tid == 0) lds->best_order = r.order;   // (read by thread 0 only, after its own store)
   return r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
 }
 
@@ -1700,6 +1702,7 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
     a.scales[row] = v1;
     if (a.ternary) a.scales[(long long)a.N + row] = v1;
     if (a.status) a.status[row] = (int)lds->n_cand;
+    if (a.trace) a.trace[row] = (int)lds->best_order;
     // diagnostics for tooling (scripts/solve_stats.py): slow slots, gathered keys, row-pass slots
     RowHeader* hw = reinterpret_cast<RowHeader*>(a.ws + (long long)row * kWsRow);
     hw->pad = lds->dbg_slow | (lds->dbg_rowpass << 16);
@@ -1790,6 +1793,14 @@ using namespace lsq;
 
 // test hooks (include/lsq_hip_debug.h, not part of the product ABI): relaxed process-wide atomics, default 0
 static std::atomic<int> g_force_streaming{0}, g_fused_debug{0};
+static std::atomic<int*> g_solver_trace{nullptr};
+// test hook: a device buffer of one int32 per row that the LS-2 / LS-T solvers (both paths) fill with the SORTED POSITION
+// of the candidate they chose (first position of its run of equal keys; n + 1 = the ternary extra candidate of
+// optimal.py:86-118; -1 = no candidate).  The caller sizes it for the largest batch it runs; null switches it off.
+extern "C" int lsq_debug_solver_trace(int32_t* device_rows) {
+  g_solver_trace.store(device_rows, std::memory_order_relaxed);
+  return 0;
+}
 extern "C" int lsq_debug_force_streaming(int on) { return g_force_streaming.exchange(on, std::memory_order_relaxed); }
 extern "C" int lsq_debug_fused_mode(int mode) { return g_fused_debug.exchange(mode, std::memory_order_relaxed); }
 
@@ -1834,6 +1845,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   a.N = g->N;
   a.ternary = scheme == LSQ_SCHEME_LST;
   a.ws = (unsigned char*)workspace;
+  a.trace = g_solver_trace.load(std::memory_order_relaxed);
   const bool solver = (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && !forced;
   // the plain sweeps (ls-1, gf-k) take an OPTIONAL workspace of lsq_sweep_workspace_bytes(N), zeroed once by the caller
   // (every launch leaves it zeroed): with it a row may be shared by several workgroups (small batches)
@@ -1861,6 +1873,7 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     f.planes = a.planes; f.plane_words = a.plane_words; f.row_words = a.row_words;
     f.scales = scales; f.N = a.N; f.ternary = a.ternary; f.debug = g_fused_debug.load(std::memory_order_relaxed);
     f.forced = forced2 ? forced : nullptr;
+    f.trace = g_solver_trace.load(std::memory_order_relaxed);
     f.greedy = (gf2 && !forced) ? 1 : 0;
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
@@ -1891,6 +1904,7 @@ extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip,
   a.flat = 1;
   a.ternary = ternary ? 1 : 0;
   a.status = status;
+  a.trace = g_solver_trace.load(std::memory_order_relaxed);
   a.scales = v12;
   a.ws = (unsigned char*)workspace;
   return run<1>(a, (hipStream_t)stream);

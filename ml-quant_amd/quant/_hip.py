@@ -79,6 +79,8 @@ def _declare(lib):
     for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode'):     # include/lsq_hip_debug.h
         getattr(lib, hook).restype = i32
         getattr(lib, hook).argtypes = [i32]
+    lib.lsq_debug_solver_trace.restype = i32
+    lib.lsq_debug_solver_trace.argtypes = [vp]
     lib.lsq_stem_conv_pool.restype = i32
     lib.lsq_stem_conv_pool.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp]
 
@@ -472,6 +474,19 @@ def xnor_impl(popcount_only: bool) -> int:
     """Test / profiling hook (include/lsq_hip_debug.h): route every XNOR convolution through the popcount kernel (True)
     or let the dispatcher pick the integer-MFMA kernel where it applies (False, the default).  Returns the old value."""
     return lib().lsq_debug_xnor_impl(int(bool(popcount_only)))
+
+
+@contextlib.contextmanager
+def solver_trace(rows: int, device):
+    """Test hook (include/lsq_hip_debug.h): inside the block every LS-2 / LS-T solve stores the sorted position of the
+    candidate it chose, one int32 per row, into the yielded tensor (read it after a synchronize)."""
+    buf = torch.full((rows,), -2, dtype=torch.int32, device=device)
+    lib().lsq_debug_solver_trace(buf.data_ptr())
+    try:
+        yield buf
+    finally:
+        torch.cuda.synchronize(device)
+        lib().lsq_debug_solver_trace(None)
 
 
 @contextlib.contextmanager

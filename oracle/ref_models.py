@@ -55,6 +55,20 @@ def _shortcut(sd, prefix, x, stride, present):
     return _bn(sd, prefix + '.1', y)
 
 
+def xnor_block_forward(sd, p, x, cfg, nl, stride, proj, chunk=0, scales_out=None):
+    """XnorBasicBlock.forward in eval mode (quant/models/resnet.py:180-190): BN -> QuantConv2d -> non-linearity with the
+    single or the double shortcut; ``p`` = the block's state_dict prefix ('' for a block on its own)."""
+    q = (p + '.') if p else ''
+    first = _nonlin(sd, q + 'nonlin1', nl[0],
+                    _qconv(sd, q + 'conv1', _bn(sd, q + 'bn1', x), cfg, stride, 1, chunk, scales_out))
+    if cfg.get('double_shortcut', False):
+        first = first + _shortcut(sd, q + 'shortcut', x, stride, proj)
+        second = _qconv(sd, q + 'conv2', _bn(sd, q + 'bn2', first), cfg, 1, 1, chunk, scales_out)
+        return _nonlin(sd, q + 'nonlin2', nl[1], second) + first
+    second = _qconv(sd, q + 'conv2', _bn(sd, q + 'bn2', first), cfg, 1, 1, chunk, scales_out)
+    return _nonlin(sd, q + 'nonlin2', nl[1], second + _shortcut(sd, q + 'shortcut', x, stride, proj))
+
+
 def resnet_forward(sd: Dict[str, torch.Tensor], arch: dict, x: torch.Tensor, chunk: int = 0,
                    scales_out: Optional[dict] = None) -> torch.Tensor:
     l0 = arch['layer0']
@@ -74,15 +88,7 @@ def resnet_forward(sd: Dict[str, torch.Tensor], arch: dict, x: torch.Tensor, chu
             p = f'blocks.{idx}'
             proj = stride != 1 or in_planes != planes
             if arch['block'] == 'xnor':
-                first = _nonlin(sd, p + '.nonlin1', nl[0],
-                                _qconv(sd, p + '.conv1', _bn(sd, p + '.bn1', x), cfg, stride, 1, chunk, scales_out))
-                if cfg.get('double_shortcut', False):
-                    first = first + _shortcut(sd, p + '.shortcut', x, stride, proj)
-                    second = _qconv(sd, p + '.conv2', _bn(sd, p + '.bn2', first), cfg, 1, 1, chunk, scales_out)
-                    x = _nonlin(sd, p + '.nonlin2', nl[1], second) + first
-                else:
-                    second = _qconv(sd, p + '.conv2', _bn(sd, p + '.bn2', first), cfg, 1, 1, chunk, scales_out)
-                    x = _nonlin(sd, p + '.nonlin2', nl[1], second + _shortcut(sd, p + '.shortcut', x, stride, proj))
+                x = xnor_block_forward(sd, p, x, cfg, nl, stride, proj, chunk, scales_out)
             else:
                 y = _nonlin(sd, p + '.nonlin1', nl[0],
                             _bn(sd, p + '.bn1', _qconv(sd, p + '.conv1', x, cfg, stride, 1, chunk, scales_out)))

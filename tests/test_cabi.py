@@ -47,7 +47,7 @@ def test_every_exported_symbol_is_declared_in_a_header(hip):
         pytest.skip('no nm on this machine')
     out = subprocess.run([nm, '-D', '--defined-only', hip.library_path()], capture_output=True, text=True, check=True).stdout
     exported = sorted({line.split()[-1] for line in out.splitlines() if ' T ' in line and line.split()[-1].startswith('lsq_')})
-    assert declared_functions(DEBUG_HEADER) == ['lsq_debug_force_streaming', 'lsq_debug_fused_mode', 'lsq_debug_xnor_impl']
+    assert declared_functions(DEBUG_HEADER) == ['lsq_debug_force_streaming', 'lsq_debug_fused_mode', 'lsq_debug_solver_trace', 'lsq_debug_xnor_impl']
     assert exported == sorted(declared_functions() + declared_functions(DEBUG_HEADER)), exported
 
 
