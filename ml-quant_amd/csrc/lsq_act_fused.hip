@@ -26,9 +26,15 @@
 // Anything the fixed-size tables cannot take (more than 40 flagged level-1 bins, table or list overflow) goes to a
 // block-level path that histograms straight from the row in memory: slow, general, exact.
 //
+// Every barrier of this file is lds_barrier() (lsq_common.h): the waves of a workgroup exchange data through LDS only --
+// each workgroup reads its own row and writes its own plane words and scales --, and the loads pass 2 requests early
+// must stay in flight across the refinement's barriers (a __syncthreads() would wait for them every time).
+//
 // Results are bit-identical to the streaming path and to oracle/lsq_exact.py (same candidate set, same
 // closed-form cost, same argmin); scripts/fused_vs_streaming.py and tests/test_gpu_parity.py check it, the rare
 // paths included (lsq_debug_fused_mode).
+
+#include <type_traits>
 
 #include "lsq_act_fused.h"
 #include "lsq_solver_math.h"
@@ -143,13 +149,13 @@ static __device__ __forceinline__ void block_excl_scan(unsigned& a, unsigned& b,
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned ia = wave_incl_scan(a), ib = wave_incl_scan(b);
   const double is = wave_incl_scan(s);
-  __syncthreads();
+  lds_barrier();
   if (lane == 63) {
     lds->wa[wid] = ia;
     lds->wb[wid] = ib;
     lds->ws[wid] = is;
   }
-  __syncthreads();
+  lds_barrier();
   unsigned oa = 0, ob = 0;
   double os = 0.0;
   ta = tb = 0;
@@ -171,9 +177,9 @@ static __device__ __forceinline__ void block_excl_scan(unsigned& a, unsigned& b,
 
 static __device__ __forceinline__ double block_sum(double v, FusedLds* lds) {
   v = wave_sum(v);
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) lds->ws[threadIdx.x >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   double t = 0.0;
   for (int w = 0; w < kWaves; ++w) t += lds->ws[w];
   return t;
@@ -219,7 +225,7 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
   FMARK(2);
   unsigned flag_base = 0;                       // flagged bins in front of the current chunk
   for (unsigned chunk = 0; chunk < tnz; chunk += kNzCap) {
-    if (chunk) __syncthreads();                 // the previous chunk's prefixes are done with
+    if (chunk) lds_barrier();                 // the previous chunk's prefixes are done with
     if (my_nz) {
       unsigned z = enz, c = ecnt;
       double sacc = esum;
@@ -242,7 +248,7 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     FMARK(3);
     // entry zl = e * kThreads + tid: with the usual few hundred non-empty bins every lane tests at most one
     for (int e = 0; e < kEntries && chunk + (unsigned)e * kThreads < tnz; ++e) {
@@ -257,8 +263,18 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
         sm = bin_sum_exact(b << L1_SHIFT, cn, h & kLowMask);
         const double vlo = (double)key_value(b << L1_SHIFT);
         const double vhi = (double)key_value((b << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        // next_hi bounds the smallest key above the bin: the upper edge of the next non-empty bin, and -- tighter, about
+        // half a bin on dense data -- that bin's MEAN, which its exact count and sum give (the minimum of a set is at
+        // most its mean; the factor covers the rounding of the quotient)
         double next_hi = vhi;
-        if (z + 1 < tnz) next_hi = (double)key_value(((unsigned)nzl[z + 1] << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+        if (z + 1 < tnz) {
+          const unsigned b2 = nzl[z + 1];
+          const unsigned long long h2 = hist1[b2];
+          const unsigned c2 = (unsigned)(h2 >> 42);
+          next_hi = (double)key_value((b2 << L1_SHIFT) | ((1u << L1_SHIFT) - 1u));
+          const double mean2 = quick_div(bin_sum_exact(b2 << L1_SHIFT, c2, h2 & kLowMask), (double)c2) * (1.0 + 1e-12);
+          next_hi = mean2 < next_hi ? mean2 : next_hi;
+        }
         fl = n >= 3u && may_hold_candidate(lds->a.nz_r0[zl], cn, lds->a.nz_p0[zl], sm, vlo, vhi, next_hi, n, total, ternary);
       }
       unsigned eflag = fl ? 1u : 0u, dummy = 0, cflag, tdummy;
@@ -281,7 +297,7 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
       flag_base += cflag;
     }
   }
-  __syncthreads();
+  lds_barrier();
   return flag_base;
 }
 
@@ -322,7 +338,7 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
   const FusedArgs& a = lds->args;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double total = lds->total;
-  __syncthreads();
+  lds_barrier();
   for (unsigned i = tid; i < nsl * (unsigned)L2_BINS; i += kThreads) (&lds->a.blk.hist2[0][0])[i] = 0ull;
   if ((unsigned)tid < nsl) {
     const Slot1 sl = lds->slot[slot_of((unsigned)tid)];
@@ -330,7 +346,7 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
     lds->blk_next[tid] = sl.next_bin == 0xFFFFu ? kNoKey : (unsigned)sl.next_bin;
     lds->blk_succs[tid] = kNoKey;
   }
-  __syncthreads();
+  lds_barrier();
   for_each_row_key(a, xrow, n, [&](unsigned key) {
     const unsigned b = key >> L1_SHIFT;
     for (unsigned j = 0; j < nsl; ++j) {
@@ -339,13 +355,13 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
       if (b == lds->blk_next[j] && key < lds->blk_succs[j]) atomicMin(&lds->blk_succs[j], key);
     }
   });
-  __syncthreads();
+  lds_barrier();
 
   // level 3 for the `pend` queued segments: one read of the row, one wave per segment
   auto flush = [&](unsigned pend) {
-    __syncthreads();
+    lds_barrier();
     for (int i = tid; i < kSeg3 * L3_BINS; i += kThreads) (&lds->a.blk.hist3[0][0])[i] = 0u;
-    __syncthreads();
+    lds_barrier();
     for_each_row_key(a, xrow, n, [&](unsigned key) {
       const unsigned p = key >> L2_SHIFT;
       for (unsigned j = 0; j < pend; ++j) {
@@ -355,7 +371,7 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
           atomicMin(&lds->succ3[j], key);
       }
     });
-    __syncthreads();
+    lds_barrier();
     if ((unsigned)wid < pend) {
       const Seg3 g = lds->seg[wid];
       const unsigned succ_s = lds->succ3[wid];
@@ -413,7 +429,7 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
         }
       }
     }
-    __syncthreads();                               // the segment records may be overwritten
+    lds_barrier();                               // the segment records may be overwritten
   };
 
   unsigned pend = 0;                               // segments queued for the next level-3 read (uniform)
@@ -429,7 +445,7 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
     double es2 = s2, ts2;
     block_excl_scan(enz2, ec2, es2, tnz2, tc2, ts2, lds);
     if (c2) lds->nzlist2[enz2] = (unsigned short)tid;
-    __syncthreads();
+    lds_barrier();
     const unsigned r02 = s1.r0 + ec2;
     const double p02 = s1.p0 + es2;
     unsigned next_sub = kNoKey;
@@ -469,7 +485,7 @@ static __device__ __forceinline__ Best resolve_slots_block(FusedLds* lds, const 
         pend = 0;
       }
     }
-    __syncthreads();                               // nzlist2 and the scan scratch are reused by the next slot
+    lds_barrier();                               // nzlist2 and the scan scratch are reused by the next slot
   }
   if (pend) flush(pend);
   return best;
@@ -701,9 +717,9 @@ static __device__ __forceinline__ void walk_key(FusedLds* lds, unsigned key, uns
 // of the row's keys) are copied to an LDS list -- table look-ups in groups of 16 independent loads, one list
 // allocation per wave -- and everything after that walks the list, so the key registers are dead before the
 // histogram atomics and the wave-level routines run.
-template <int NK>
+template <int NK, class Early>
 static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n, unsigned tflag, bool ternary, Best best,
-                                                const unsigned (&kreg)[NK]) {
+                                                const unsigned (&kreg)[NK], Early keys_dead) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int i = tid; i < L1_BINS / 2 + 1; i += kThreads) reinterpret_cast<unsigned*>(lds->b.role)[i] = 0u;
   for (int i = tid; i < kNodeCap * 64; i += kThreads) (&lds->b.centry[0][0])[i] = 0u;
@@ -717,7 +733,7 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
     lds->n_list = 0;
     lds->slow_mask = 0ull;
   }
-  __syncthreads();
+  lds_barrier();
   if (wid == 0) {
     // bins whose keys no longer fit the list go to the block path (ascending bin order; tflag <= kFastSlots <= 64).
     // A listed bin brings the bin right above it along (its smallest key is the bin's successor): 2 x cnt bounds it.
@@ -750,7 +766,7 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   // One sweep over the key registers, 16 at a time: table look-ups (independent loads), one ballot per key, ONE
   // list allocation per wave and group, then every kept key goes to base + (kept lanes below it).  Padding keys
   // (kNoKey) index the always-zero extra table entry.
@@ -785,8 +801,19 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
         }
       }
     }
+    // This group's 16 key registers are dead: pass 2's early loads take their place, a few per group, so that the
+    // request is spread over the whole copy phase (see pass2_request_part).
+    {
+      constexpr int NG = (NK + G - 1) / G;
+      const int gi = g0 / G;
+      unsigned parts = 0;
+#pragma unroll
+      for (int k = 0; k < kPfParts; ++k)
+        if (k * NG / kPfParts == gi) parts |= 1u << k;
+      if (parts) keys_dead(parts);
+    }
   }
-  __syncthreads();
+  lds_barrier();
   FMARK(5);
   const unsigned n_list = lds->n_list;
   unsigned cur_lo = 0, cur_n = tflag, tp_lo = 0, tp_n = 0;
@@ -794,7 +821,7 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
     if (round) {
       for (unsigned i = tid; i < cur_n * 64u; i += kThreads) (&lds->b.nhist[0][0])[i] = 0ull;
       for (unsigned i = tid; i < tp_n; i += kThreads) lds->task_fill[tp_lo + i] = 0u;
-      __syncthreads();
+      lds_barrier();
     }
     // list pass: the table look-ups of 8 keys in flight.  Round 0: every key of a flagged bin into its node's
     // histogram, keys of a successor bin into the cell minimum.  Later rounds: the (rare) non-zero depth-0 entries
@@ -853,7 +880,7 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
         atomicAdd(&lds->b.nhist[nd - 1u][(top_key >> 12) & 63u],
                   (unsigned long long)top_cnt * kOne + (unsigned long long)top_cnt * (unsigned long long)(top_key & 0xFFFu));
     }
-    __syncthreads();
+    lds_barrier();
     if (round == 0) FMARK(6);
     if (round == 1) FMARK(11);
     const unsigned items = cur_n + tp_n;
@@ -863,7 +890,7 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
       else
         resolve_task(lds, n, tp_lo + (it - cur_n), ternary, best);
     }
-    __syncthreads();
+    lds_barrier();
     if (round == 0) FMARK(7);
     if (round == 1) FMARK(12);
     cur_lo += cur_n;
@@ -895,7 +922,7 @@ static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
     if (better(o, best)) best = o;
   }
   if (lane == 0) lds->wbest[wid] = best;
-  __syncthreads();
+  lds_barrier();
   if (wid == 0) {
     Best r = lds->wbest[lane & (kWaves - 1)];
 #pragma unroll
@@ -911,13 +938,14 @@ static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
       lds->best_order = r.order;
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 // Everything between the level-1 histogram and v1.  `each_key` as in refine_resident.
-template <int NK>
+template <int NK, class Early, class Drop>
 static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const float* __restrict__ xrow, unsigned n, unsigned minkey,
-                                                 unsigned maxkey, bool ternary, const unsigned (&kreg)[NK]) {
+                                                 unsigned maxkey, bool ternary, const unsigned (&kreg)[NK], Early keys_dead,
+                                                 Drop early_drop, bool& early_ok) {
   const int tid = threadIdx.x;
   const unsigned bin_lo = min(minkey >> L1_SHIFT, (unsigned)L1_BINS - 1u), bin_hi = min(maxkey >> L1_SHIFT, (unsigned)L1_BINS - 1u);
   if (tid == 0) lds->maxkey = maxkey;
@@ -932,10 +960,12 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
   FMARK(4);
   unsigned nslot, round0 = 0;
   bool listed = false;
+  bool requested = false;                        // pass 2's early loads are out (and still wanted)
   if (tflag <= (unsigned)kFastSlots && !(lds->args.debug & 1)) {
     nslot = 0;
     if (tflag) {
-      best = refine_resident<NK>(lds, n, tflag, ternary, best, kreg);
+      best = refine_resident<NK>(lds, n, tflag, ternary, best, kreg, keys_dead);
+      requested = true;
       nslot = lds->n_slow;
       listed = true;
     }
@@ -943,15 +973,22 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
   } else {
     nslot = min((unsigned)kSlotCap, tflag);
   }
-  while (nslot) {
-    for (unsigned q = 0; q < nslot; q += kBlkSlots)
-      best = resolve_slots_block(lds, xrow, n, min((unsigned)kBlkSlots, nslot - q),
-                                 [&](unsigned j) { return listed ? (unsigned)lds->slow[q + j] : q + j; }, ternary, best);
-    round0 += kSlotCap;
-    if (round0 >= tflag) break;
-    l1_scan(lds, n, round0, ternary, bin_lo, bin_hi);
-    nslot = min((unsigned)kSlotCap, tflag - round0);
+  if (nslot) {
+    // (the block path needs the whole register file: what was requested early is dropped -- pass 2 loads it again --,
+    // so that nothing is kept alive, or spilled, across this rare path)
+    for (;;) {
+      for (unsigned q = 0; q < nslot; q += kBlkSlots)
+        best = resolve_slots_block(lds, xrow, n, min((unsigned)kBlkSlots, nslot - q),
+                                   [&](unsigned j) { return listed ? (unsigned)lds->slow[q + j] : q + j; }, ternary, best);
+      round0 += kSlotCap;
+      if (round0 >= tflag) break;
+      l1_scan(lds, n, round0, ternary, bin_lo, bin_hi);
+      nslot = min((unsigned)kSlotCap, tflag - round0);
+    }
+    requested = false;
+    early_drop();
   }
+  early_ok = requested;
   // ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
   if (ternary && n > 0u && tid == 0) {
     const double mean = lds->total / (double)n;
@@ -971,12 +1008,12 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
 static __device__ __forceinline__ void block_minmax(unsigned& mn, unsigned& mx, FusedLds* lds) {
   mn = wave_min(mn);
   mx = ~wave_min(~mx);
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) {
     lds->wa[threadIdx.x >> 6] = mn;
     lds->wb[threadIdx.x >> 6] = mx;
   }
-  __syncthreads();
+  lds_barrier();
   mn = kNoKey;
   mx = 0u;
   for (int w = 0; w < kWaves; ++w) {
@@ -1012,18 +1049,90 @@ static __device__ __forceinline__ void push_bits(unsigned& w0, unsigned& w1, flo
       : "vcc");
 }
 
-// full 64-channel groups: every channel index is a compile-time constant
-template <int VEC, bool AFFINE>
+// Pass-2 data requested EARLY (single-launch kernel): the first kPfFloats floats of the lane's first item, issued when
+// the key registers die -- after the copy phase of the refinement -- so that they arrive during the refinement rounds
+// and the argmin, a 10-15 us stretch in which the CU otherwise issues no load at all.
+#ifndef LSQ_PB
+#define LSQ_PB 4
+#endif
+template <int VEC>
+struct Pf {
+  static constexpr int UB = VEC == 1 ? 64 : 32 / VEC;     // channels per batch of loads (as in pass2_full)
+  static constexpr int NB = 64 / UB;
+  static constexpr int PB = VEC == 1 ? 1 : (NB < LSQ_PB ? NB : LSQ_PB);   // batches requested early: 128 floats (VEC = 1: the item's 64)
+  float v[PB][UB][VEC];
+};
+
+// Loads [K, K + 1) / kPfParts of the early request.  The request is dealt out in kPfParts parts over the copy phase of
+// the refinement (refine_resident), one or two behind every group of 16 key registers that phase has finished with: a
+// CU keeps only some 50-60 KB of loads in flight, so a wave that asks for its 128 floats AT ONCE sits in the issue of
+// those loads until most of the 256 KB of its workgroup have arrived -- measured: the phase behind the request grew by
+// exactly what pass 2 saved.  An eighth at a time (32 KB per CU) fits, and the copy runs meanwhile.
+static constexpr int kPfParts = 8;
+template <int VEC, int K>
+static __device__ __forceinline__ void pass2_request_part(const float* __restrict__ q0, int HW, Pf<VEC>& pf) {
+  constexpr int L = Pf<VEC>::PB * Pf<VEC>::UB;                       // loads of the whole request
+  constexpr int lo = K * L / kPfParts, hi = (K + 1) * L / kPfParts;
+#pragma unroll
+  for (int i = lo; i < hi; ++i) {
+    constexpr int UB = Pf<VEC>::UB;
+    const float* __restrict__ q = q0 + (long long)i * HW;
+    const int b = i / UB, u = i % UB;
+    if constexpr (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(q);
+      pf.v[b][u][0] = t.x; pf.v[b][u][1 % VEC] = t.y; pf.v[b][u][2 % VEC] = t.z; pf.v[b][u][3 % VEC] = t.w;
+    } else if constexpr (VEC == 2) {
+      const float2 t = *reinterpret_cast<const float2*>(q);
+      pf.v[b][u][0] = t.x; pf.v[b][u][1 % VEC] = t.y;
+    } else {
+      pf.v[b][u][0] = *q;
+    }
+  }
+}
+
+// parts: bit mask of the parts to request now
+template <int VEC>
+static __device__ __forceinline__ void pass2_request(const FusedArgs& a, const float* __restrict__ xrow, int item0, Pf<VEC>& pf,
+                                                     unsigned parts) {
+  const int HW = a.H * a.W;
+  const int PV = (HW + VEC - 1) / VEC;
+  const int items = a.Gt * PV;
+  if (item0 >= items) return;
+  const int j = item0 / PV;
+  const int p = (item0 - j * PV) * VEC;
+  const int grp = j / a.Gg;
+  const int jj = j - grp * a.Gg;
+  const int c0 = grp * a.cg + jj * 64;
+  const float* __restrict__ q = xrow + (long long)c0 * HW + p;
+  if (parts & 1u) pass2_request_part<VEC, 0>(q, HW, pf);               // (compile-time masks at every call site)
+  if (parts & 2u) pass2_request_part<VEC, 1>(q, HW, pf);
+  if (parts & 4u) pass2_request_part<VEC, 2>(q, HW, pf);
+  if (parts & 8u) pass2_request_part<VEC, 3>(q, HW, pf);
+  if (parts & 16u) pass2_request_part<VEC, 4>(q, HW, pf);
+  if (parts & 32u) pass2_request_part<VEC, 5>(q, HW, pf);
+  if (parts & 64u) pass2_request_part<VEC, 6>(q, HW, pf);
+  if (parts & 128u) pass2_request_part<VEC, 7>(q, HW, pf);
+}
+
+// full 64-channel groups: every channel index is a compile-time constant.  PRE: the caller may hold the first batches
+// of the lane's first item (pass2_request; `have_pre` is uniform over the workgroup).
+template <int VEC, bool AFFINE, bool PRE = false>
 static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const float* bn_s, const float* bn_t,
                                                     const float* __restrict__ xrow, float v1,
                                                     unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1,
-                                                    int item0, int item_step) {
+                                                    int item0, int item_step, const Pf<VEC>* pre = nullptr, bool have_pre = false) {
   const int HW = a.H * a.W;
   const int PV = (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   const float alpha = a.alpha >= 0.f ? a.alpha : INFINITY;
   double acc = 0.0;
-  for (int item = item0; item < items; item += item_step) {
+  // loads per batch; two batches in flight.  One pixel per lane (the short rows): all 64 channels at once --
+  // those launches are bound by memory round trips per lane, not by bytes
+  constexpr int UB = Pf<VEC>::UB;
+  constexpr int NB = Pf<VEC>::NB;
+  constexpr int PB = Pf<VEC>::PB;
+  auto one_item = [&](int item, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;    // the batches b < PB are already in `pre`
     const int j = item / PV;
     const int p = (item - j * PV) * VEC;
     const int grp = j / a.Gg;
@@ -1039,12 +1148,8 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
       w0[v][0] = w0[v][1] = w1[v][0] = w1[v][1] = 0u;
       facc[v] = 0.f;
     }
-    // loads per batch; two batches in flight.  One pixel per lane (the short rows): all 64 channels at once --
-    // those launches are bound by memory round trips per lane, not by bytes
-    constexpr int UB = VEC == 1 ? 64 : 32 / VEC;
-    constexpr int NB = 64 / UB;
     float buf[2][UB][VEC];
-    const float* __restrict__ q = src;                 // running channel pointer (no table of 64 addresses)
+    const float* __restrict__ q = src + (FIRST ? (long long)PB * UB * HW : 0ll);   // running channel pointer (no table of 64 addresses)
     auto load = [&](int which, int) {
 #pragma unroll
       for (int u = 0; u < UB; ++u, q += HW) {
@@ -1059,13 +1164,14 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
         }
       }
     };
-    load(0, 0);
+    if constexpr (!FIRST) load(0, 0);
+    else if constexpr (PB < NB) load(PB & 1, PB);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       // (the scheduling barriers keep exactly two batches of loads in flight: without them the scheduler hoists all
       // 64 channels' loads to the top and spills)
       __builtin_amdgcn_sched_barrier(0);
-      if (b + 1 < NB) load((b + 1) & 1, b + 1);
+      if (b + 1 < NB && (!FIRST || b + 1 > PB)) load((b + 1) & 1, b + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
@@ -1077,7 +1183,9 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
         }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          float xv = buf[b & 1][u][v];
+          float xv;
+          if constexpr (FIRST) xv = b < PB ? pre->v[b < PB ? b : 0][u][v] : buf[b & 1][u][v];
+          else xv = buf[b & 1][u][v];
           if constexpr (AFFINE) xv = fmaf(xv, sc, sh);
           const float d = fminf(fabsf(xv), alpha) - v1;
           push_bits(w0[v][cc >> 5], w1[v][cc >> 5], facc[v], xv, d);
@@ -1096,7 +1204,15 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
         prow1[widx] = (unsigned long long)__brev(w1[v][0]) | ((unsigned long long)__brev(w1[v][1]) << 32);
       }
     }
+  };
+  int item = item0;
+  if constexpr (PRE) {
+    if (have_pre && item < items) {                    // (uniform condition; lanes without an item skip)
+      one_item(item, std::true_type{});
+      item += item_step;
+    }
   }
+  for (; item < items; item += item_step) one_item(item, std::false_type{});
   return acc;
 }
 
@@ -1195,7 +1311,7 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
       lds->bn_t[i] = a.pre_shift[i];
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   const int HW = a.H * a.W;
   const long long M = a.row_elems;
@@ -1284,16 +1400,36 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   FMARK(1);
   const unsigned n = (unsigned)((M + 2) / 3);
   const bool ternary = a.ternary != 0;
-  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, maxkey, ternary, kreg);
+  // The first 128 floats of the lane's first pass-2 item are requested as soon as the refinement has copied the keys
+  // it needs out of the registers (the usual path; rows that take the block path load them in pass 2 as before).
+  const bool full = (a.cg & 63) == 0 && a.C <= kBnCap;
+  Pf<VEC> pf;
+  bool have_pf = false;
+  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, maxkey, ternary, kreg, [&](unsigned parts) {
+#ifndef LSQ_NO_EARLY
+    if (full) pass2_request<VEC>(a, xrow, tid, pf, parts);
+#endif
+  }, [&]() {
+#pragma unroll
+    for (int b = 0; b < Pf<VEC>::PB; ++b)
+#pragma unroll
+      for (int u = 0; u < Pf<VEC>::UB; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) pf.v[b][u][v] = 0.f;
+  }, have_pf);
+  have_pf = have_pf && full;
+#ifdef LSQ_NO_EARLY
+  have_pf = false;
+#endif
 
   FMARK(9);
   // pass 2: both planes and sum |x - v1 b1|
   unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
   unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
   double acc;
-  if ((a.cg & 63) == 0 && a.C <= kBnCap) {
-    acc = affine ? pass2_full<VEC, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads)
-                 : pass2_full<VEC, false>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads);
+  if (full) {
+    acc = affine ? pass2_full<VEC, true, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads, &pf, have_pf)
+                 : pass2_full<VEC, false, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads, &pf, have_pf);
   } else {
     acc = pass2_any<VEC>(a, xrow, v1, prow0, prow1, tid, kThreads);
   }
@@ -1329,7 +1465,7 @@ __global__ __launch_bounds__(T) void aq_forced_kernel(FusedArgs a) {
       bn_s[i] = a.pre_scale[i];
       bn_t[i] = a.pre_shift[i];
     }
-    __syncthreads();
+    lds_barrier();
   }
   const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
   unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
@@ -1365,15 +1501,15 @@ __global__ __launch_bounds__(T) void aq_greedy2_kernel(FusedArgs a) {
       bn_t[i] = a.pre_shift[i];
     }
   }
-  __syncthreads();
+  lds_barrier();
   const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
   const long long M = a.row_elems;
   const int HW = a.H * a.W;
   auto block_total = [&](double v) {
     v = wave_sum(v);
-    __syncthreads();
+    lds_barrier();
     if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     double t = 0.0;
     for (int w = 0; w < T / 64; ++w) t += red[w];
     return t;
@@ -1458,9 +1594,13 @@ int launch_forced(const FusedArgs& a, int vec, hipStream_t st) {
 
 template <int T, int U>
 int launch(const FusedArgs& a, int vec, hipStream_t st) {
+#ifdef LSQ_DEV_VEC      // developer builds: one instantiation only (register-pressure experiments compile in seconds)
+  hipLaunchKernelGGL((aq_fused_kernel<T, U, LSQ_DEV_VEC>), dim3(a.N), dim3(T), 0, st, a);
+#else
   if (vec == 4) hipLaunchKernelGGL((aq_fused_kernel<T, U, 4>), dim3(a.N), dim3(T), 0, st, a);
   else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2>), dim3(a.N), dim3(T), 0, st, a);
   else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1>), dim3(a.N), dim3(T), 0, st, a);
+#endif
   return (int)hipGetLastError();
 }
 
@@ -1493,11 +1633,15 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
   if (a.greedy) return launch_greedy<T>(a, vec, st);
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
+#ifdef LSQ_DEV_U
+  return need <= LSQ_DEV_U ? launch<T, LSQ_DEV_U>(a, vec, st) : kFusedNotEligible;
+#else
   if (need <= 5) return launch<T, 5>(a, vec, st);
   if (need <= 9) return launch<T, 9>(a, vec, st);
   if (need <= 17) return launch<T, 17>(a, vec, st);
   if (need <= 33) return launch<T, 33>(a, vec, st);
   return kFusedNotEligible;
+#endif
 }
 
 #ifdef LSQ_PHASE_CLOCKS

@@ -11,6 +11,14 @@ namespace lsq {
 
 constexpr int kWave = 64;
 
+// Workgroup barrier for phases whose waves talk to each other through LDS only.  __syncthreads() is a release fence +
+// s_barrier + acquire fence, and on gfx950 the release fence drains the vector-memory counter too: every global load
+// in flight is waited for at every barrier.  A kernel that requests data early and keeps it in flight across a chain
+// of LDS-only phases needs the barrier without that drain: LDS operations of a CU complete in order, so
+// lgkmcnt(0) + s_barrier is all the ordering those phases need.  (The asm is a compiler barrier for memory operations;
+// registers with loads pending are still tracked by the compiler, which waits for them at their first use.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float clamp_sym(float x, float alpha) {
   // torch.clamp(x, -alpha, alpha); a negative alpha encodes clamp_identity
   return alpha >= 0.f ? fminf(fmaxf(x, -alpha), alpha) : x;

@@ -72,14 +72,20 @@ __device__ __forceinline__ MPair m_pair_quick(double lo_cnt, double lo_sum, doub
   return r;
 }
 
-// Can a position inside [r0, r0+cnt) be a candidate (optimal.py:78-80)?  Conservative.
+// Can a position inside [r0, r0+cnt) be a candidate (optimal.py:78-80)?  Conservative, never misses one.
+// The keys of the bin lie in [vlo, vhi]; the first key above it is at most next_hi.  m2(i) and m1(i) grow with i.
+// A position i whose successor is in the same bin needs vlo <= m(i) <= vhi, and m over the bin's positions lies between
+// m_lo (taken one position in front of the bin) and m_hi (at the bin's last position): m_hi >= vlo and m_lo <= vhi.
+// The bin's LAST position has its successor above the bin: vlo <= m_hi <= next_hi.  (Until round 4 the test was
+// m_hi >= vlo and m_lo <= next_hi -- it let every bin within one bin width below a crossing through, twelve flagged
+// level-1 bins for the two that hold the candidates of a Gaussian row.)
 __device__ inline bool may_hold_candidate(unsigned r0, unsigned cnt, double p0, double s, double vlo, double vhi,
                                    double next_hi, unsigned n, double total, bool ternary) {
   const long long r1 = (long long)r0 + cnt;
   const long long ilo = r0 > 1u ? (long long)r0 : 1ll;
   const long long ihi = (r1 - 1) < ((long long)n - 2) ? (r1 - 1) : ((long long)n - 2);
   if (ilo > ihi) return false;
-  double m2_lo, m1_lo, m2_hi, m1_hi, succ_hi;
+  double m2_lo, m1_lo, m2_hi, m1_hi;
   if (r0 >= 1u) {
     const MPair m = m_pair_quick((double)r0, p0, (double)n, total);
     m2_lo = m.m2;
@@ -87,19 +93,20 @@ __device__ inline bool may_hold_candidate(unsigned r0, unsigned cnt, double p0, 
   } else {
     m2_lo = m1_lo = 0.5 * quick_div(total - vhi, (double)n - 1.0);
   }
-  if (r1 <= (long long)n - 1) {
+  const bool has_last = r1 <= (long long)n - 1;    // the bin's last position is an inner position of the row
+  if (has_last) {
     const MPair m = m_pair_quick((double)r1, p0 + s, (double)n, total);
     m2_hi = m.m2;
     m1_hi = m.m1;
-    succ_hi = next_hi;
   } else {
+    // the bin holds the row's largest key: the last inner position is n - 2, its upper tail is that one key (<= vhi)
+    // and its lower head sums to total - (largest key) <= total - vlo
     m2_hi = 0.5 * vhi;
-    m1_hi = vhi;
-    succ_hi = vhi;
+    m1_hi = 0.5 * (quick_div(total - vlo, (double)n - 1.0) + vhi);
   }
   const double up = 1.0 + kSlack, dn = 1.0 - kSlack;
-  bool hit = (m2_hi * up >= vlo) && (m2_lo * dn <= succ_hi);
-  if (!ternary) hit = hit || ((m1_hi * up >= vlo) && (m1_lo * dn <= succ_hi));
+  bool hit = (m2_hi * up >= vlo) && ((m2_lo * dn <= vhi) || (has_last && m2_hi * dn <= next_hi));
+  if (!ternary) hit = hit || ((m1_hi * up >= vlo) && ((m1_lo * dn <= vhi) || (has_last && m1_hi * dn <= next_hi)));
   return hit;
 }
 

@@ -64,8 +64,11 @@ def may_hold_candidate(r0: int, cnt: int, p0: float, s: float, vlo: float, vhi: 
                        next_hi: float, n: int, total: float, ternary: bool) -> bool:
     """Conservative test: can a position i in [r0, r0+cnt) be a candidate?
 
-    m1 and m2 are non-decreasing in i, so over the bin they lie between their values at the
-    bin's boundary ranks, which are exact.  ``next_hi`` bounds a[i+1] from above.
+    m1 and m2 are non-decreasing in i.  The keys of the bin lie in [vlo, vhi]; ``next_hi`` bounds the first key above
+    the bin.  A position whose successor sits in the same bin needs vlo <= m(i) <= vhi, and m over the bin's positions
+    lies between its value one position in front of the bin (m_lo) and at the bin's last position (m_hi); the bin's
+    last position has its successor above the bin and needs vlo <= m_hi <= next_hi.  (Same test as
+    ml-quant_amd/csrc/lsq_solver_math.h since round 4.)
     """
     r1 = r0 + cnt
     if max(r0, 1) > min(r1 - 1, n - 2):
@@ -74,16 +77,15 @@ def may_hold_candidate(r0: int, cnt: int, p0: float, s: float, vlo: float, vhi: 
         m2_lo, m1_lo = m_pair(r0, p0, n, total)
     else:
         m2_lo = m1_lo = 0.5 * (total - vhi) / (n - 1)
-    if r1 <= n - 1:
+    has_last = r1 <= n - 1
+    if has_last:
         m2_hi, m1_hi = m_pair(r1, p0 + s, n, total)
-        succ_hi = next_hi
     else:
-        m2_hi, m1_hi = 0.5 * vhi, vhi
-        succ_hi = vhi
+        m2_hi, m1_hi = 0.5 * vhi, 0.5 * ((total - vlo) / (n - 1) + vhi)
     up, dn = 1.0 + SLACK, 1.0 - SLACK
-    hit = (m2_hi * up >= vlo) and (m2_lo * dn <= succ_hi)
+    hit = (m2_hi * up >= vlo) and ((m2_lo * dn <= vhi) or (has_last and m2_hi * dn <= next_hi))
     if not ternary:
-        hit = hit or ((m1_hi * up >= vlo) and (m1_lo * dn <= succ_hi))
+        hit = hit or ((m1_hi * up >= vlo) and ((m1_lo * dn <= vhi) or (has_last and m1_hi * dn <= next_hi)))
     return hit
 
 
