@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 7
+#define LSQ_ABI_VERSION 8
 
 /* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
 #define LSQ_ACT_NONE 0
@@ -130,6 +130,25 @@ int64_t lsq_sweep_workspace_bytes(int64_t rows);
 int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,
                    float clamp_alpha, float* v12, int32_t* status, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/*
+ * Training-side pieces of the quantizers (ABI v8).  Rows are samples (activations, M = C*H*W)
+ * or output channels (weights, M = C/groups*KH*KW; clamp_alpha < 0); scales [k][rows] are the sign planes' scales
+ * (LS2: v1, v2;  LST: v1, v1;  LS1: v1;  GF: v1..vk;  k = 0: full precision, the clamp alone).
+ *
+ * lsq_quant_values: x_q = sum_i v_i b_i with b_i = sign(clamp(x) - sum_{r<i} v_r b_r) -- the tensor the
+ *   reference's quantizers return (quantization.py:56, :89-92, :112-115, :137-146), the fp32 operand of the
+ *   weight-gradient convolution in training.
+ * lsq_ste_backward: grad_x = d<grad_q, x_q>/dx through the straight-through estimator of every sign
+ *   (quant/binary/ste.py:51-66: the gradient passes where the sign's argument lies in [-1, 1]) and the symmetric
+ *   clamp (quantization.py:22-24: passes inside [-alpha, alpha]); no gradient flows through the scales (the
+ *   reference computes them from detached data, quantization.py:53, :77, :109, :133).
+ * rows <= 65535.
+ */
+int lsq_quant_values(const float* x, int64_t rows, int64_t M, int k, const float* scales, float clamp_alpha,
+                     float* x_q, void* stream);
+int lsq_ste_backward(const float* x, const float* grad_q, int64_t rows, int64_t M, int k, const float* scales,
+                     float clamp_alpha, float* grad_x, void* stream);
 
 /*
  * Weight sign packing with cached per-output-channel scales (eval mode):

@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -79,6 +79,10 @@ def _declare(lib):
     for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode'):     # include/lsq_hip_debug.h
         getattr(lib, hook).restype = i32
         getattr(lib, hook).argtypes = [i32]
+    lib.lsq_quant_values.restype = i32
+    lib.lsq_quant_values.argtypes = [vp, i64, i64, i32, vp, f32, vp, vp]
+    lib.lsq_ste_backward.restype = i32
+    lib.lsq_ste_backward.argtypes = [vp, vp, i64, i64, i32, vp, f32, vp, vp]
     lib.lsq_debug_solver_trace.restype = i32
     lib.lsq_debug_solver_trace.argtypes = [vp]
     lib.lsq_stem_conv_pool.restype = i32
@@ -468,6 +472,36 @@ def pointwise_conv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
         check(lib().lsq_pointwise_conv(x.data_ptr(), n, c, h, wd, w.data_ptr(), ptr(None if bias is None else _f32c(bias)), o,
                                        int(stride), y.data_ptr(), stream_ptr(x.device)), 'lsq_pointwise_conv')
     return y
+
+
+def quant_values(x: torch.Tensor, scales: Optional[torch.Tensor], alpha: float) -> torch.Tensor:
+    """x_q = sum_i v_i b_i of the quantizer chain for rows x[r] (dim 0) and plane scales [k, rows] (None: the clamp
+    alone) -- what the reference's quantizer_* functions return, on the device in one pass."""
+    x = _f32c(x)
+    rows, m = x.shape[0], x.numel() // max(x.shape[0], 1)
+    k = 0 if scales is None else scales.shape[0]
+    sc = None if scales is None else _f32c(scales)
+    out = torch.empty_like(x)
+    with _on(x), _Timed('lsq_quant_values', 8 * x.numel(), 0):
+        check(lib().lsq_quant_values(x.data_ptr(), rows, m, k, ptr(sc), float(alpha), out.data_ptr(), stream_ptr(x.device)),
+              'lsq_quant_values')
+    return out
+
+
+def ste_backward(x: torch.Tensor, grad_q: torch.Tensor, scales: Optional[torch.Tensor], alpha: float) -> torch.Tensor:
+    """Gradient with respect to ``x`` of <grad_q, quantizer(clamp(x))> through the straight-through estimator
+    (quant/binary/ste.py:51-66) and the clamp; rows = dim 0, plane scales [k, rows] (None: the clamp alone)."""
+    x, grad_q = _f32c(x), _f32c(grad_q)
+    if grad_q.shape != x.shape:
+        raise ValueError(f'gradient of shape {tuple(grad_q.shape)} for an input of shape {tuple(x.shape)}')
+    rows, m = x.shape[0], x.numel() // max(x.shape[0], 1)
+    k = 0 if scales is None else scales.shape[0]
+    sc = None if scales is None else _f32c(scales)
+    out = torch.empty_like(x)
+    with _on(x), _Timed('lsq_ste_backward', 12 * x.numel(), 0):
+        check(lib().lsq_ste_backward(x.data_ptr(), grad_q.data_ptr(), rows, m, k, ptr(sc), float(alpha), out.data_ptr(),
+                                     stream_ptr(x.device)), 'lsq_ste_backward')
+    return out
 
 
 def xnor_impl(popcount_only: bool) -> int:

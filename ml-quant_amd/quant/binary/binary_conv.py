@@ -12,7 +12,10 @@ Dispatch of ``forward``:
     then an XNOR-popcount convolution (binary activations) or a bf16-MFMA convolution
     (fp activations) against weight sign planes packed once per ``eval()`` session.  There is
     no fallback on this branch: a missing library or a failed launch raises.
-  * anything else (CPU tensors, training) -> the torch formulation in ``quant.binary``.
+  * CUDA tensor in ``train()`` mode, plain geometry -> the same kernels for the forward and the kernels of
+    ``quant.binary.hip_train`` for the backward (straight-through estimator, transposed sign-weight convolution), one
+    ``torch.autograd.Function`` per call;
+  * anything else (CPU tensors, grouped / dilated training convolutions) -> the torch formulation in ``quant.binary``.
 """
 
 import re
@@ -96,9 +99,16 @@ class QuantConv2d(nn.Conv2d):
         raise ValueError(f'{kind} is not a valid clamping function.')
 
     # ------------------------------------------------------------------ forward
+    #: train-mode CUDA tensors through the kernels (False: the torch formulation, e.g. to compare the two in tests)
+    hip_train = True
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self._wants_hip(x):
             return self._forward_hip(x)
+        if self.training and self.hip_train and x.is_cuda:
+            from quant.binary import hip_train
+            if hip_train.supported(self, x):
+                return hip_train.train_step_forward(self, x)
         return self._forward_torch(x)
 
     def _forward_torch(self, x: torch.Tensor) -> torch.Tensor:

@@ -1,4 +1,8 @@
-"""The evaluation loop (inference side of the reference's ``quant/common/training.py``).
+"""The training and evaluation loops of the reference's ``quant/common/training.py``.
+
+``train`` follows ``training.py:66-152``: one optimizer step and one scheduler step per batch, optional knowledge
+distillation from a teacher, metrics on the training outputs, hooks once per batch.  On a GPU every train-mode
+``QuantConv2d`` runs its forward and backward through the gfx950 kernels (``quant.binary.hip_train``).
 
 ``evaluate`` follows ``training.py:155-204``: ``model.eval()``, metrics reset, ``torch.no_grad()``, one forward
 per batch of the test loader, metrics updated on the device, hooks called once at the end.  The reference runs
@@ -6,7 +10,6 @@ multi-GPU evaluation through ``nn.DataParallel``; here, when a process group is 
 GPU), every rank takes its slice of each batch and the logits are all-gathered before the metrics see them
 (``quant.common.sharded_eval``), so every rank reports the metrics of the whole test set.
 
-Training (``train``, :66-152) is outside this build's scope (the path is the eval forward).
 """
 
 import logging
@@ -52,6 +55,57 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
     return computed
 
 
-def train(*args, **kwargs):
-    raise NotImplementedError('training is outside the scope of this build (inference path only): run the drivers '
-                              'with --skip-training')
+def _get_lr(optimizer) -> float:
+    for group in optimizer.param_groups:
+        return group['lr']
+    raise ValueError('Cannot get optimizer LR: optimizer does not have any parameter groups.')
+
+
+def project(optimizer) -> None:
+    """Placeholder kept for interface parity (training.py:55-63: projecting the latent weights to [-1, 1] made no
+    difference in the reference's experiments, so it is a no-op there too)."""
+    return None
+
+
+def train(model: nn.Module, train_loader, metrics: Dict[str, Metric], optimizer, scheduler, device: torch.device,
+          epoch: int, log_interval: int, hooks: Optional[Sequence[Hook]] = None,
+          teacher: Optional[nn.Module] = None) -> Dict[str, float]:
+    """One epoch over ``train_loader``; returns {metric name: value} of the training outputs.
+
+    ``model.loss_fn(output, target)`` is the criterion, or ``model.loss_fn(output, teacher_output, target)`` when a
+    ``teacher`` is given (knowledge distillation).  The scheduler steps once per batch, as in the reference."""
+    hooks = hooks or []
+    model.train()
+    for metric in metrics.values():
+        metric.reset()
+    loss_fn = model.module.loss_fn if isinstance(model, nn.DataParallel) else model.loss_fn
+    seen = 0
+    for batch_idx, (data, target) in enumerate(train_loader):
+        data, target = data.to(device), target.to(device)
+        optimizer.zero_grad()
+        output = model(data)
+        if teacher is None:
+            teacher_output = None
+            loss = loss_fn(output, target)
+        else:
+            teacher_output = teacher(data)
+            loss = loss_fn(output, teacher_output, target)
+        loss.backward()
+        optimizer.step()
+        project(optimizer)
+        scheduler.step()
+        with torch.no_grad():
+            for metric in metrics.values():
+                metric.update(output, target, teacher_output=teacher_output)
+        for hook in hooks:
+            hook(epoch=epoch, global_step=1 + (epoch - 1) * len(train_loader.dataset) + batch_idx,
+                 values_dict={'lr': _get_lr(optimizer)}, log_interval=log_interval)
+        seen += len(data)
+        if batch_idx % log_interval == 0:
+            logger.info('Train Epoch: {} [{}/{} ({:.0f}%)]\tBatch Loss: {:.6f}'.format(
+                epoch, seen, len(train_loader.dataset), 100 * batch_idx / len(train_loader), loss.item()))
+    computed = {name: metric.compute() for name, metric in metrics.items()}
+    logger.info('Training set evaluation metrics:')
+    for name, metric in metrics.items():
+        logger.info(f'{name}: {metric}')
+    return computed

@@ -104,3 +104,163 @@ def test_trace_is_off_by_default_and_after_the_block():
     hip.solve_rows(rows.to(DEV), 3, False)
     torch.cuda.synchronize()
     assert (trace.cpu() == -7).all()                   # the hook is cleared: nothing writes to the old buffer
+
+
+# ------------------------------------------------------------------------------------------------ training
+def _chain(x, scales, alpha):
+    """The quantizer chain in torch: value and the straight-through gradient's closed form (tests/test_training.py pins
+    this formula to autograd through the reference-equal torch formulation)."""
+    inside = (x >= -alpha) & (x <= alpha) if alpha >= 0 else torch.ones_like(x, dtype=torch.bool)
+    c = x.clamp(-alpha, alpha) if alpha >= 0 else x
+    shape = (-1,) + (1,) * (x.dim() - 1)
+    r, d = torch.zeros_like(c), []
+    for v in scales:
+        di = c - r
+        d.append(di)
+        r = r + v.view(shape) * torch.where(di >= 0, 1.0, -1.0)
+
+    def grad(g):
+        G, acc = g.clone(), torch.zeros_like(g)
+        for v, di in zip(reversed(scales), reversed(d)):
+            t = torch.where(di.abs() <= 1, G * v.view(shape), torch.zeros_like(G))
+            acc = acc + t
+            G = G - t
+        return torch.where(inside, acc if len(scales) else g, torch.zeros_like(g))
+    return (r if len(scales) else c), grad
+
+
+@pytest.mark.parametrize('shape', [(5, 16, 6, 6), (3, 7, 5, 3), (24, 32, 3, 3), (2, 1, 1, 9)])
+@pytest.mark.parametrize('k', [0, 1, 2, 3])
+def test_ste_kernels_equal_the_torch_chain(shape, k):
+    """lsq_quant_values (bit for bit) and lsq_ste_backward (1e-6) against the chain in torch, for activations (clamp) and
+    weight-shaped rows (no clamp), row lengths with and without 16-byte rows, +-0, values on the clamp and on the |d| = 1
+    edge of the estimator."""
+    hip = _hip()
+    x = detgen.normal(f'r4.ste.x.{shape}.{k}', shape, scale=1.3)
+    x.view(-1)[::11] = 0.0
+    x.view(-1)[3::13] = -0.0
+    x.view(-1)[5::17] = 2.0
+    x.view(-1)[7::19] = -2.0
+    g = detgen.normal(f'r4.ste.g.{shape}.{k}', shape)
+    scales = [detgen.uniform(f'r4.ste.v{i}.{shape}', (shape[0],), 0.2, 1.1) for i in range(k)]
+    if k:
+        x.view(-1)[9::23] = 1.0 + float(scales[0][0])                       # |d_1| = 1 exactly in row 0
+    for alpha in (2.0, -1.0):
+        want, grad = _chain(x, scales, alpha)
+        sc = torch.stack(scales).to(DEV) if k else None
+        got = hip.quant_values(x.to(DEV), sc, alpha).cpu()
+        assert torch.equal(got, want), (shape, k, alpha)
+        gx = hip.ste_backward(x.to(DEV), g.to(DEV), sc, alpha).cpu()
+        assert torch.allclose(gx, grad(g), rtol=1e-6, atol=1e-7), (shape, k, alpha, float((gx - grad(g)).abs().max()))
+    with pytest.raises(Exception):
+        hip.ste_backward(x.to(DEV), g[:1].to(DEV), None, 2.0)
+
+
+TRAIN_CASES = [('ls-2', 'ls-1', 1, True), ('ls-1', 'ls-1', 2, True), ('gf-2', 'ls-1', 1, False), ('ls-T', 'ls-1', 2, True),
+               ('fp', 'ls-1', 1, True), ('ls-1', 'gf-2', 1, True), ('ls-1', 'ls-2', 2, False), ('ls-2', 'ls-T', 1, True)]
+
+
+@pytest.mark.parametrize('xs,ws,stride,bias', TRAIN_CASES)
+def test_train_step_on_the_kernels_equals_the_torch_formulation(xs, ws, stride, bias):
+    """One train-mode step of QuantConv2d through quant.binary.hip_train (forward on lsq_act_quant + lsq_xnor_conv2d /
+    lsq_signw_conv2d, backward on lsq_signw_conv2d (transposed) + lsq_ste_backward) against the SAME module on the torch
+    formulation on the device (autograd through STESign, the graph the f9_train fixture pins to the reference): output,
+    the three gradients, the cached weight scales."""
+    from quant.binary.binary_conv import QuantConv2d
+    clamp = {'kind': 'symmetric', 'alpha': 2}
+    convs = []
+    for hip_path in (True, False):
+        conv = QuantConv2d(xs, ws, 32, 48, 3, clamp, stride=stride, padding=1, bias=bias)
+        with torch.no_grad():
+            conv.weight.copy_(detgen.normal('r4.train.w', conv.weight.shape, scale=0.3))
+            if bias:
+                conv.bias.copy_(detgen.normal('r4.train.b', conv.bias.shape, scale=0.1))
+        conv.hip_train = hip_path
+        convs.append(conv.to(DEV).train())
+    out = []
+    for conv in convs:
+        x = detgen.normal('r4.train.x', (4, 32, 13, 10), scale=1.2).to(DEV).requires_grad_()
+        gy_shape = (4, 48, (13 - 1) // stride + 1, (10 - 1) // stride + 1)
+        y = conv(x)
+        assert tuple(y.shape) == gy_shape
+        y.backward(detgen.normal('r4.train.gy', gy_shape).to(DEV))
+        out.append((x, y, conv))
+    (x1, y1, c1), (x2, y2, c2) = out
+    assert type(y1.grad_fn).__name__ == '_QuantConv2dStepBackward' and type(y2.grad_fn).__name__ != '_QuantConv2dStepBackward'
+
+    def rel(a, b):
+        a, b = a.detach(), b.detach()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(y1, y2) <= 1e-5, rel(y1, y2)
+    assert rel(x1.grad, x2.grad) <= 2e-5, rel(x1.grad, x2.grad)             # (bf16 hi + lo terms of the transposed convolution)
+    assert rel(c1.weight.grad, c2.weight.grad) <= 1e-5, rel(c1.weight.grad, c2.weight.grad)
+    if bias:
+        assert rel(c1.bias.grad, c2.bias.grad) <= 1e-5
+    for (n1, b1), (n2, b2) in zip(c1.w_approximate.named_buffers(), c2.w_approximate.named_buffers()):
+        assert n1 == n2 and torch.equal(b1, b2) and float(b1.abs().sum()) > 0, n1
+
+
+@pytest.mark.parametrize('mode', ['eval_only', 'train_and_eval'])
+def test_train_step_moving_average_modes_on_the_kernels(mode):
+    """activation_quantization.py:72-88 in training: the moving average tracks the batch's mean scales; 'train_and_eval'
+    quantizes with the tracked values.  Kernels against the torch formulation over three steps."""
+    from quant.binary.binary_conv import QuantConv2d
+    convs = []
+    for hip_path in (True, False):
+        conv = QuantConv2d('ls-2', 'ls-1', 32, 32, 3, {'kind': 'symmetric', 'alpha': 3}, mode, 0.9, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(detgen.normal('r4.ma.w', conv.weight.shape, scale=0.3))
+            conv.bias.copy_(detgen.normal('r4.ma.b', conv.bias.shape, scale=0.1))
+        conv.hip_train = hip_path
+        convs.append(conv.to(DEV).train())
+    for step in range(3):
+        ys = []
+        for conv in convs:
+            x = detgen.normal(f'r4.ma.x{step}', (3, 32, 8, 8), scale=1.1).to(DEV).requires_grad_()
+            y = conv(x)
+            y.sum().backward()
+            ys.append((y, x.grad))
+        assert float((ys[0][0] - ys[1][0]).abs().max()) <= 1e-5 * float(ys[1][0].abs().max())
+        assert float((ys[0][1] - ys[1][1]).abs().max()) <= 2e-5 * float(ys[1][1].abs().max())
+        ma = [c.x_approximate.moving_avg_module.moving_average for c in convs]
+        assert torch.allclose(ma[0], ma[1], rtol=2e-6), (step, ma)
+
+
+def test_training_loop_on_the_gpu_takes_the_kernels():
+    """quant.common.training.train on cuda:0 (training.py:66-152): every quantized layer of a small XNOR ResNet runs its
+    step on the kernels, the loss falls, and two steps from the same start match the torch formulation's two steps."""
+    import quant.binary.hip_train as HT
+    from quant.binary.binary_conv import QuantConv2d
+    from quant.common.initialization import get_lr_scheduler, get_optimizer
+    from quant.common.metrics import LossMetric
+    from quant.common.training import train
+    from quant.models.resnet import QResNet
+    layer = {'x_quant': 'ls-2', 'w_quant': 'ls-1', 'clamp': {'kind': 'symmetric', 'alpha': 3}, 'double_shortcut': True}
+    arch = {'moving_average_mode': 'off', 'moving_average_momentum': 0.99, 'block': 'xnor',
+            'layer0': {'n_in_channels': 16, 'kernel_size': 3, 'stride': 1, 'padding': 1, 'bias': False, 'maxpool': {'type': 'identity'}},
+            'layer1': layer, 'layer2': layer, 'layer3': layer, 'layer4': layer, 'nonlins': ['relu', 'relu'],
+            'num_blocks': [1, 1, 1, 1], 'output_classes': 10}
+    g = torch.Generator().manual_seed(5)
+    data = torch.randn(64, 3, 16, 16, generator=g)
+    target = torch.randint(0, 10, (64,), generator=g)
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, target), batch_size=16)
+    calls = []
+    orig = HT.train_step_forward
+    losses = {}
+    try:
+        HT.train_step_forward = lambda conv, x: (calls.append(conv), orig(conv, x))[1]
+        for hip_path in (True, False):
+            torch.manual_seed(11)
+            model = QResNet(loss_fn=torch.nn.functional.cross_entropy, **arch).to(DEV)
+            for m in model.modules():
+                if isinstance(m, QuantConv2d):
+                    m.hip_train = hip_path
+            opt = get_optimizer(model.parameters(), {'algorithm': 'sgd', 'lr': 0.02, 'momentum': 0.9})
+            sched = get_lr_scheduler(opt, {'scheduler': 'step_lr', 'step_size': 10, 'gamma': 0.5}, 3, len(loader))
+            metrics = {'Loss': LossMetric(model.loss_fn, accumulate=True)}
+            losses[hip_path] = [train(model, loader, metrics, opt, sched, torch.device(DEV), e, 100)['Loss'] for e in (1, 2, 3)]
+    finally:
+        HT.train_step_forward = orig
+    assert len(calls) == 8 * 4 * 3                              # 8 quantized layers x 4 batches x 3 epochs, kernels only
+    assert losses[True][2] < losses[True][0]
+    assert losses[True][0] == pytest.approx(losses[False][0], rel=2e-2)      # (a binarized net amplifies fp32 reassociation)

@@ -111,9 +111,15 @@ def test_skip_training_task_and_checkpoint_on_cpu(tmp_path):
     assert len(tgt) == 200
     assert test[0]['Top-1 Accuracy'] == pytest.approx(float((out.argmax(1) == tgt).float().mean()))
     assert test[0]['Loss'] == pytest.approx(float(torch.nn.functional.nll_loss(out, tgt)), rel=1e-5)
-    cfg2 = dict(cfg, skip_training=False)
-    with pytest.raises(NotImplementedError):
-        classification_task(cfg2, tmp_path, MNISTDataLoader)
+    # without --skip-training the task trains (tasks.py:195-228): two epochs, metrics per epoch, a checkpoint per epoch
+    cfg2 = json.loads(json.dumps(dict(cfg, skip_training=False)))
+    cfg2['optimization']['epochs'] = 2
+    cfg2['log']['save_model_freq'] = 1
+    cfg2['experiment_name'] = 'e2'
+    tr, te = classification_task(cfg2, tmp_path, MNISTDataLoader)
+    assert len(tr) == len(te) == 2 and set(tr[0]) == {'Loss', 'Top-1 Accuracy', 'Top-5 Accuracy'}
+    assert tr[1]['Loss'] < tr[0]['Loss']                                    # it learns its 200 synthetic samples
+    assert (tmp_path / 'e2' / 'checkpoints' / 'checkpoint_2.pt').exists()
 
 
 def test_driver_script_runs_a_config(tmp_path):
