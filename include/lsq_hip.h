@@ -103,10 +103,11 @@ int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
  *   planes       out, [k] activation planes laid out as described above (halo pre-zeroed)
  *   scales       out, [k][N] fp32: v1..vk per sample (LST: row 1 repeats v1)
  *   workspace    LS2 / LST without forced scales: lsq_solver_workspace_bytes(N) bytes, 8-byte aligned (required).
- *                LS1 / GF without forced scales: NULL, or lsq_sweep_workspace_bytes(N) bytes, 8-byte aligned, ZEROED
- *                by the caller before its first use (every call leaves it zeroed again; one buffer per stream):
- *                with it a row may be shared by several workgroups when the batch alone would leave CUs idle --
- *                same planes, the scale is the same fixed-order sum either way.
+ *                LS1 / GF without forced scales: NULL, or lsq_sweep_workspace_bytes(N) bytes, 8-byte aligned, one
+ *                buffer per stream, ANY content (the arrival slots are tagged with a per-launch epoch, so neither
+ *                zero-filling nor the leftovers of an aborted launch matter): with it a row may be shared by several
+ *                workgroups when the batch alone would leave CUs idle -- same planes, the scale is the same
+ *                fixed-order sum either way.
  */
 int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
                   float clamp_alpha, const float* pre_scale, const float* pre_shift,

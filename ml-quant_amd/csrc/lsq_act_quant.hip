@@ -86,7 +86,8 @@ struct Args {
   double qmagic;            // != 0: exact row sums -- every 8-channel group sum is rounded to a multiple of 2^e through
                             // (g + qmagic) - qmagic, qmagic = 1.5 * 2^(52 + e), and fp64 adds such multiples exactly
   unsigned char* ws;        // workspace (kWsRow bytes per row)
-  unsigned char* rws;       // row-split sweeps: kSplitRow bytes per row (partial sums + arrival counter), zero between launches
+  unsigned char* rws;       // row-split sweeps: kSplitRow bytes per row (partial sums + (epoch, arrivals) slot); any content
+  unsigned epoch;           // row-split sweeps: tag of this sweep launch (never 0), see the arrival slot
 };
 constexpr int kMaxParts = 8;
 constexpr int kSplitRow = 8 * (kMaxParts + 1);           // bytes: kMaxParts fp64 partial sums + a 64-bit slot for the counter
@@ -1611,19 +1612,24 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
   LSQ_MARK(7);
   if (a.write_scale && tid == 0) {
     if (!HIST && a.parts > 1) {
-      // the row's workgroups leave their partial sums and take a ticket; the last one adds them up in part order
-      // (the same sum whichever workgroup comes last) and leaves the counter at zero for the next launch
+      // the row's workgroups leave their partial sums and count themselves in; the last one adds the partials up in
+      // part order (the same sum whichever workgroup comes last).  The 64-bit slot is (launch epoch << 32 | arrivals):
+      // the first arrival of a launch finds another epoch -- whatever an earlier call, an aborted launch or an
+      // uninitialised buffer left there -- and restarts the count, so the workspace needs no zero-filling and a stale
+      // counter can never keep a scale from being written.
       double* partial = reinterpret_cast<double*>(a.rws + (long long)row * kSplitRow);
-      unsigned* counter = reinterpret_cast<unsigned*>(partial + kMaxParts);
+      unsigned long long* slot = reinterpret_cast<unsigned long long*>(partial + kMaxParts);
       __hip_atomic_store(&partial[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __atomic_thread_fence(__ATOMIC_RELEASE);
-      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket == (unsigned)a.parts - 1u) {
+      unsigned long long seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+      do {
+        want = (unsigned)(seen >> 32) == a.epoch ? seen + 1ull : (((unsigned long long)a.epoch << 32) | 1ull);
+      } while (!__hip_atomic_compare_exchange_strong(slot, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      if ((unsigned)want == (unsigned)a.parts) {
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         double t = 0.0;
         for (int p = 0; p < a.parts; ++p) t += __hip_atomic_load(&partial[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.scales[(long long)q * a.N + row] = (float)(t / (double)a.row_elems);
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);
@@ -1713,8 +1719,15 @@ __global__ __launch_bounds__(kThreads) void aq_solve_kernel(Args a) {
   }
 }
 
+// tag of a row-split sweep launch (the arrival slot's epoch): unique per launch of this process, never 0
+static std::atomic<unsigned> g_sweep_epoch{0x5eed0001u};
+
 template <int VEC>
-int launch_sweep(const Args& a, int q, bool hist, hipStream_t st) {
+int launch_sweep(const Args& a_in, int q, bool hist, hipStream_t st) {
+  Args a = a_in;
+  do {
+    a.epoch = g_sweep_epoch.fetch_add(1u, std::memory_order_relaxed);
+  } while (a.epoch == 0u);
   const dim3 grid = (!hist && a.parts > 1) ? dim3((unsigned)a.parts, (unsigned)a.N) : dim3((unsigned)a.N);
   const dim3 block(kThreads);
   if (hist) hipLaunchKernelGGL((aq_sweep_kernel<VEC, true, 0>), grid, block, 0, st, a, q);
@@ -1732,7 +1745,7 @@ int run(Args a, hipStream_t st) {
   if (!a.flat) {
     const long long items = (long long)a.Gt * ((a.H * a.W + VEC - 1) / VEC);
     // Workgroups per row (row-split sweeps): when the batch alone leaves CUs idle (small batches), up to kMaxParts
-    // workgroups share a row, at most one workgroup per CU over the batch.  Needs the caller's zeroed row
+    // workgroups share a row, at most one workgroup per CU over the batch.  Needs the caller's row
     // workspace and a scale to reduce (the plain sweeps of ls-1 / gf-k; not the histogram sweep, not forced scales).
     // (measured, scripts/sweep_split.py: up to 32 rows every shape gains -- 56 x 56 x 64: 30 -> 11 us --; from 33 to 128
     //  rows only rows of half a megabyte and more do, two workgroups each; beyond, one workgroup per row fills the chip)
@@ -1847,8 +1860,8 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
   a.ws = (unsigned char*)workspace;
   a.trace = g_solver_trace.load(std::memory_order_relaxed);
   const bool solver = (scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && !forced;
-  // the plain sweeps (ls-1, gf-k) take an OPTIONAL workspace of lsq_sweep_workspace_bytes(N), zeroed once by the caller
-  // (every launch leaves it zeroed): with it a row may be shared by several workgroups (small batches)
+  // the plain sweeps (ls-1, gf-k) take an OPTIONAL workspace of lsq_sweep_workspace_bytes(N) (any content): with it a row
+  // may be shared by several workgroups (small batches)
   a.rws = (!solver && !forced && workspace && (long long)workspace_bytes >= (long long)g->N * kSplitRow && ((uintptr_t)workspace % 8) == 0)
               ? (unsigned char*)workspace : nullptr;
   if (solver) {

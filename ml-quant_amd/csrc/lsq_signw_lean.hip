@@ -580,9 +580,13 @@ int launch_items(int items, bool odd, int nres, dim3 grid, hipStream_t st, const
   return (int)hipGetLastError();
 }
 
-bool lean_geometry(const lsq_conv_geom* g) {
-  return g->groups == 1 && g->KH * g->KW == kTaps && g->C % kPC == 0 && g->C <= kLeanMaxPre && g->H * g->W >= 4;
+// what the prepared weight image depends on: channels, out-channels, taps (never the batch or the image size -- a module
+// caches the image across input shapes)
+bool lean_weights(const lsq_conv_geom* g) {
+  return g->groups == 1 && g->KH * g->KW == kTaps && g->C % kPC == 0 && g->C <= kLeanMaxPre;
 }
+// what a launch needs on top: at least one group of four pixels per image plane
+bool lean_geometry(const lsq_conv_geom* g) { return lean_weights(g) && g->H * g->W >= 4; }
 
 // One pass over a period of the tile / image alignment pattern, with the kernel's own arithmetic: the largest patch
 // (padded linear positions between the first and the last one a workgroup's pixels and taps touch) and the largest
@@ -650,13 +654,13 @@ int items_of(long long groups) {
 }  // namespace
 
 long long lean_weight_bytes(const lsq_conv_geom* g, int planes) {
-  if (!lean_geometry(g)) return 0;
+  if (!lean_weights(g)) return 0;
   const long long opad64 = (g->O + 63) / 64 * 64;
   return (long long)planes * (g->C / kPC) * kTaps * opad64 * kPRow;
 }
 
 int lean_prepare(const uint64_t* wbits, int planes, const lsq_conv_geom* g, void* wprep, hipStream_t st) {
-  if (!lean_geometry(g)) return LSQ_E_UNSUPPORTED;
+  if (!lean_weights(g)) return LSQ_E_UNSUPPORTED;
   const int opad64 = (g->O + 63) / 64 * 64, opad16 = (g->O + 15) / 16 * 16;
   const int cchunks = g->C / kPC, Gg = (g->C + 63) / 64;
   const long long rows = (long long)planes * cchunks * kTaps * opad64;

@@ -66,6 +66,10 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&t)[SPL
   f32x2 r = {x0, x1};
   if constexpr (HALF) {
     static_assert(SPLIT == 2, "fp16 terms: two");
+    // operands outside the fp16 domain are REPORTED (the overflow flag: the caller switches to the bf16 split); they are
+    // also saturated here, so that a batch that slips through before the report is read yields finite numbers, not inf / nan
+    r[0] = __builtin_amdgcn_fmed3f(r[0], -kHalfMax, kHalfMax);
+    r[1] = __builtin_amdgcn_fmed3f(r[1], -kHalfMax, kHalfMax);
     const f16x2 h = __builtin_convertvector(r, f16x2);
     t[0] = __builtin_bit_cast(unsigned, h);
     r = (r - __builtin_convertvector(h, f32x2)) * kLoScale;

@@ -216,6 +216,14 @@ class _Timed:
 
 
 _ws_cache = {}
+_WS_CACHE_MAX = 16      # (device, stream) entries kept per cache: streams come and go (one per captured graph)
+
+
+def _remember(cache: dict, key, buf):
+    cache.pop(key, None)
+    cache[key] = buf                          # (insertion order = age: the oldest entries go first)
+    while len(cache) > _WS_CACHE_MAX:
+        cache.pop(next(iter(cache)))
 
 
 def solver_workspace(rows: int, device) -> torch.Tensor:
@@ -229,16 +237,15 @@ def solver_workspace(rows: int, device) -> torch.Tensor:
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty((need,), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        _remember(_ws_cache, key, buf)
     return buf
 
 
 _sweep_ws_cache = {}
 
-
 def sweep_workspace(rows: int, device) -> torch.Tensor:
     """Row workspace of the ls-1 / gf-k sweeps (partial sums + arrival counters of rows shared by several workgroups):
-    zeroed here once, left zeroed by every call; cached per (device, stream) like the solver's."""
+    any content (the arrival slots carry a per-launch epoch); cached per (device, stream) like the solver's."""
     need = lib().lsq_sweep_workspace_bytes(rows)
     device = torch.device(device)
     if device.index is None:
@@ -247,7 +254,7 @@ def sweep_workspace(rows: int, device) -> torch.Tensor:
     buf = _sweep_ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.zeros((need,), dtype=torch.uint8, device=device)
-        _sweep_ws_cache[key] = buf
+        _remember(_sweep_ws_cache, key, buf)
     return buf
 
 
@@ -416,6 +423,17 @@ def stem_overflow_tripped(device) -> bool:
         st['event'] = None
         if int(st['host'][0]) != 0:
             st['tripped'] = True
+    return st['tripped']
+
+
+def stem_overflow_check(device) -> bool:
+    """Blocking form of :func:`stem_overflow_tripped`: waits for the device and reads the flag itself -- for the end of an
+    evaluation loop and in front of a graph capture, where a report that is 16 calls late would be too late."""
+    st = _stem_guard_state(device)
+    torch.cuda.synchronize(device)
+    st['event'] = None
+    if int(st['flag'].item()) != 0:
+        st['tripped'] = True
     return st['tripped']
 
 

@@ -48,6 +48,11 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
                 metric.update(output, target)
     for hook in hooks:
         hook(epoch=epoch, global_step=1 + (epoch - 1) * len(test_loader.dataset) + batch_idx)
+    if torch.device(device).type == 'cuda':
+        from quant import _hip
+        if _hip.available() and _hip.stem_overflow_check(device):
+            logger.warning('lsq_stem_conv_pool saw operands at or beyond 65504 during this evaluation: those batches were '
+                           'computed on saturated operands; the stem has switched to the bf16 split')
     computed = {name: metric.compute() for name, metric in metrics.items()}
     logger.info('Test set evaluation metrics:')
     for name, metric in metrics.items():

@@ -296,6 +296,10 @@ def test_stem_fp16_split_reports_out_of_range_operands_and_the_model_falls_back(
             assert not hip.stem_overflow_tripped(DEV) and bool(torch.isfinite(good).all())
             xb = x.clone()
             xb[1, 2, 10, 11] = 1e5                                          # un-normalised 16-bit image data, say
+            first = model.blocks[0](xb)                                     # the batch that slips through: computed on the
+            assert bool(torch.isfinite(first).all())                        # SATURATED operand (round 4): finite, and
+            assert hip.stem_overflow_check(DEV)                             # the blocking check reports it at once
+            hip.stem_overflow_reset(DEV)
             for _ in range(17):                                             # fp16 split: inf / nan around that pixel, which the
                 model.blocks[0](xb)                                         # ReLU / max-pool can turn into wrong finite values;
                 torch.cuda.synchronize()                                    # the sticky flag travels to the host with every
@@ -382,6 +386,13 @@ def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
         # under a clamp the row sums are exact (multiples of 2^e added in fp64): the same scale bit for bit however the
         # row was dealt to lanes and workgroups, and whatever the batch size
         assert torch.equal(s0, s1) and torch.equal(s1, s2)
+        # a workspace full of garbage (a caller's recycled scratch, the leftovers of an aborted launch): the arrival slots
+        # are tagged with a per-launch epoch, so every scale is still written, and written right (round 4)
+        junk = torch.randint(0, 256, (lib.lsq_sweep_workspace_bytes(n),), dtype=torch.uint8, device=DEV)
+        junk.view(torch.int64)[8::9] = 0x7fffffff00000003                    # a plausible stale (epoch, arrivals) pair
+        p3, s3 = call(junk)
+        p4, s4 = call(junk)
+        assert torch.equal(p3, p0) and torch.equal(s3, s0) and torch.equal(p4, p0) and torch.equal(s4, s0)
         xs = x[:1].contiguous()
         geom1 = hip.make_geom(1, c, h, w, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
         pl1 = torch.zeros((k * hip.act_plane_words(geom1),), dtype=torch.int64, device=DEV)
@@ -392,7 +403,8 @@ def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
                                      sc1.data_ptr(), ws1.data_ptr(), ws1.numel(), hip.stream_ptr(x.device)) == 0
         torch.cuda.synchronize()
         assert torch.equal(sc1.cpu()[:, 0], s1[:, 0]), (ci, sc1, s1[:, 0])
-        assert int(ws.sum()) == 0 or bool((ws.view(-1, 72)[:, 64:] == 0).all())      # counters back at zero
+        slots = ws.view(-1, 72)[:, 64:].contiguous().view(torch.int64).cpu()                   # (epoch << 32 | arrivals) per row
+        assert int(ws.sum()) == 0 or bool(((slots & 0xffffffff) <= 8).all() and ((slots >> 32) != 0).all())
 
 
 def test_greedy_two_bit_single_launch_kernel():
