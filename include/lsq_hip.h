@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 8
+#define LSQ_ABI_VERSION 9
 
 /* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
 #define LSQ_ACT_NONE 0
@@ -131,6 +131,21 @@ int64_t lsq_sweep_workspace_bytes(int64_t rows);
 int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,
                    float clamp_alpha, float* v12, int32_t* status, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/*
+ * QuantConv2d.forward with 1-bit (LS1) activations on SMALL images in one launch (ABI v9): quantizer_ls_1
+ * (quantization.py:35-56) and F.conv2d (binary_conv.py:165-173) fused -- the activation scale v1[n] = mean|clamp(x[n])|
+ * only enters the epilogue, so one workgroup per sample (and out-channel slice) packs the sign plane into LDS, reduces
+ * the row sum and convolves from LDS; no plane or scale round trip through memory (cifar100_ls1_kd.yaml: 32 launches of
+ * the two-kernel path become 16).  Arguments as lsq_act_quant (x, g, clamp_alpha, pre_scale / pre_shift) and
+ * lsq_xnor_conv2d (weight planes, epilogue); scales [1][N] out.  Results are bit-identical to lsq_act_quant(LS1) +
+ * lsq_xnor_conv2d.  Covered: groups 1, dilation 1, kernels up to 3x3, C a multiple of 64 up to 512, H*W a multiple
+ * of 4 up to 1024, clamp_alpha > 0, x 16-byte aligned; otherwise LSQ_E_UNSUPPORTED (take the two entry points).
+ */
+int lsq_ls1_conv2d(const float* x, const lsq_conv_geom* g, float clamp_alpha, const float* pre_scale,
+                   const float* pre_shift, const uint64_t* wbits, const int32_t* wsum, int kw_planes,
+                   const float* wscales, const float* bias, int act, const float* act_slope,
+                   const float* res_pre, const float* res_post, float* y, float* scales, void* stream);
 
 /*
  * Training-side pieces of the quantizers (ABI v8).  Rows are samples (activations, M = C*H*W)

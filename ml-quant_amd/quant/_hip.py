@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -79,6 +79,8 @@ def _declare(lib):
     for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode'):     # include/lsq_hip_debug.h
         getattr(lib, hook).restype = i32
         getattr(lib, hook).argtypes = [i32]
+    lib.lsq_ls1_conv2d.restype = i32
+    lib.lsq_ls1_conv2d.argtypes = [vp, gp, f32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.lsq_quant_values.restype = i32
     lib.lsq_quant_values.argtypes = [vp, i64, i64, i32, vp, f32, vp, vp]
     lib.lsq_ste_backward.restype = i32
@@ -342,6 +344,33 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
+
+
+E_UNSUPPORTED = -6
+
+
+def ls1_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wsum: torch.Tensor, wscales: torch.Tensor,
+               bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor, scales: torch.Tensor, pre: Optional[tuple] = None,
+               relu: bool = False, res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
+               prelu: Optional[torch.Tensor] = None) -> bool:
+    """ls-1 quantizer + XNOR convolution in ONE launch for small images (lsq_ls1_conv2d); ``scales`` [1, N] receives the
+    activation scales.  Returns False -- nothing launched -- when the geometry is not covered (the caller then takes
+    act_quant + xnor_conv2d, which give the same bits)."""
+    x = _f32c(x)
+    act, slope = _act(relu, prelu, geom.O)
+    m = geom.C * geom.H * geom.W
+    nres = (res_pre is not None) + (res_post is not None)
+    macs = y.numel() * geom.C * geom.KH * geom.KW * wscales.shape[0]
+    with _on(x), _Timed('lsq_ls1_conv2d', 4 * geom.N * m + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
+                         4 * geom.N * m + 4 * y.numel()):
+        code = lib().lsq_ls1_conv2d(x.data_ptr(), ctypes.byref(geom), float(alpha), None if pre is None else pre[0].data_ptr(),
+                                    None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
+                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), act, ptr(slope), ptr(res_pre), ptr(res_post),
+                                    y.data_ptr(), scales.data_ptr(), stream_ptr(x.device))
+    if code == E_UNSUPPORTED:
+        return False
+    check(code, 'lsq_ls1_conv2d')
+    return True
 
 
 def signw_prepare_weight(wbits: torch.Tensor, planes: int, geom: ConvGeom) -> Optional[torch.Tensor]:

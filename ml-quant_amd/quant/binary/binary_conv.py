@@ -99,6 +99,10 @@ class QuantConv2d(nn.Conv2d):
         raise ValueError(f'{kind} is not a valid clamping function.')
 
     # ------------------------------------------------------------------ forward
+    #: ls-1 activations on images of at most 1024 pixels, eager launches: one fused quantize + convolve launch (False:
+    #: always the two kernels)
+    fuse_small = True
+
     #: train-mode CUDA tensors through the kernels (False: the torch formulation, e.g. to compare the two in tests)
     hip_train = True
 
@@ -238,6 +242,17 @@ class QuantConv2d(nn.Conv2d):
             return y
         xq = self.x_approximate
         k = xq.n_planes
+        if (self.x_quant == 'ls-1' and self.fuse_small and xq.eval_scales(n) is None and h * w <= 1024
+                and not torch.cuda.is_current_stream_capturing()):
+            # small images (CIFAR), eager launches: quantizer and convolution in ONE launch, no plane round trip
+            # (csrc/lsq_ls1_fused.hip) -- the forward is host-bound there and half the launches are worth more than the
+            # kernels' speed (measured: 94 k -> 116 k images/s eager at batch 100); under graph capture the host does not
+            # matter and the two specialised kernels are faster (181 k against 115 k images/s), so a capture takes those.
+            # Same bits either way.
+            scales = torch.empty((1, n), dtype=torch.float32, device=x.device)
+            if _hip.ls1_conv2d(x, self._alpha(), wbits, wsum, wscales, bias, geom, y, scales, pre, relu, res_pre, res_post, prelu):
+                self.last_act_scales = scales
+                return y
         # (one workspace per launch stream: two streams through one module must not share planes and scales)
         key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device,
                torch.cuda.current_stream(x.device).cuda_stream)
