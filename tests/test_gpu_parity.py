@@ -224,7 +224,7 @@ def _solver_diag(rows, skip, ternary):
     r = rows.shape[0]
     v12, _ = hip.solve_rows(torch.from_numpy(rows).to(DEV), skip, ternary)
     torch.cuda.synchronize()
-    ws_row = hip.lib().lsq_solver_workspace_bytes(1)
+    ws_row = hip.lib().lsq_solver_workspace_bytes(201) - hip.lib().lsq_solver_workspace_bytes(200)   # bytes of one row record
     ws = hip.solver_workspace(r, DEV)[:r * ws_row].cpu().numpy().reshape(r, ws_row)
     hdr = ws[:, :16].copy().view(np.uint32).reshape(r, 4)
     return v12[0].cpu().numpy(), hdr[:, 0], hdr[:, 3] & 0xFFFF, hdr[:, 3] >> 16
