@@ -27,9 +27,6 @@ int lsq_debug_force_streaming(int on);
 /* single-launch quantizer: 1 = every flagged bin through its block path, 2 = key list of 2048 entries (default 0) */
 int lsq_debug_fused_mode(int mode);
 
-/* 0: batches of up to 64 rows of the LS-2 / LS-T schemes under a clamp take the row-split sweeps (rows shared by several
- * workgroups; bit-identical results, measured slower); default 1: they take the single-launch kernel like large batches */
-int lsq_debug_no_row_split(int on);
 /* device buffer of one int32 per row (sized by the caller for its largest batch; NULL = off, the default): every
  * LS-2 / LS-T solve -- lsq_act_quant and lsq_solve_rows, single-launch and streaming path -- stores the SORTED POSITION of
  * the candidate it chose (quant/binary/optimal.py:151: the argmin's element of the ascending sub-sample; the first

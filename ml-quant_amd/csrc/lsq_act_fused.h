@@ -21,7 +21,6 @@ struct FusedArgs {
   int ternary;
   int debug;                // developer / test switches: 1 every flagged bin through the block path, 2 a 2048-key list
   const float* forced;      // [2][N] scales given by the caller (moving-average inference): no solve, planes only
-  double qmagic;            // != 0 (a clamp is set): exact sum of |x - v1 b1| -- octet sums rounded to multiples of 2^e
   int* trace;               // test hook: chosen sorted position per row (lsq_debug_solver_trace), or null
   int greedy;               // gf-2 (quantization.py:118-148 with k = 2): v1 = mean |x| instead of the solve; planes and
                             // v2 = mean |x - v1 b1| are the 2-bit least-squares scheme's

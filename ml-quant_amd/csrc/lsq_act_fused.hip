@@ -1125,7 +1125,6 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
   const int PV = (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   const float alpha = a.alpha >= 0.f ? a.alpha : INFINITY;
-  const bool exact = a.qmagic != 0.0;
   double acc = 0.0;
   // loads per batch; two batches in flight.  One pixel per lane (the short rows): all 64 channels at once --
   // those launches are bound by memory round trips per lane, not by bytes
@@ -1190,15 +1189,6 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
           if constexpr (AFFINE) xv = fmaf(xv, sc, sh);
           const float d = fminf(fabsf(xv), alpha) - v1;
           push_bits(w0[v][cc >> 5], w1[v][cc >> 5], facc[v], xv, d);
-          if ((cc & 7) == 7) {
-            // EXACT row sum under a clamp (qmagic != 0; lsq_act_quant.hip, plain sweeps): the fp32 sum of every octet of
-            // channels (fixed membership and order) is rounded to a multiple of 2^e and fp64 adds those without rounding --
-            // the second scale is the same NUMBER whichever kernel, lane dealing or row split produced it
-            if (exact) {
-              acc += ((double)facc[v] + a.qmagic) - a.qmagic;
-              facc[v] = 0.f;
-            }
-          }
         }
       }
     }
@@ -1281,17 +1271,13 @@ static __device__ __forceinline__ double pass2_any(const FusedArgs& a, const flo
             w0[v] |= (unsigned long long)b0 << cc;
             w1[v] |= (unsigned long long)(r >= 0.f) << cc;
             facc[v] += fabsf(r);
-            if ((cc & 7) == 7 && a.qmagic != 0.0) {        // (exact row sum: see pass2_full)
-              acc += ((double)facc[v] + a.qmagic) - a.qmagic;
-              facc[v] = 0.f;
-            }
           }
         }
       }
     }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      acc += a.qmagic != 0.0 ? ((double)facc[v] + a.qmagic) - a.qmagic : (double)facc[v];     // (a last group of fewer than 8)
+      acc += (double)facc[v];
       const int pix = p + v;
       if (pix < HW) {
         const int h = pix / a.W;

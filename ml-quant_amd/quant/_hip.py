@@ -76,7 +76,7 @@ def _declare(lib):
     lib.lsq_pool_bias_relu_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]
     lib.lsq_pointwise_conv.restype = i32
     lib.lsq_pointwise_conv.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
-    for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode', 'lsq_debug_no_row_split'):     # include/lsq_hip_debug.h
+    for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode'):     # include/lsq_hip_debug.h
         getattr(lib, hook).restype = i32
         getattr(lib, hook).argtypes = [i32]
     lib.lsq_ls1_conv2d.restype = i32
@@ -572,7 +572,7 @@ def solver_trace(rows: int, device):
 
 @contextlib.contextmanager
 def debug_switches(xnor_popcount: Optional[bool] = None, force_streaming: Optional[bool] = None,
-                   fused_mode: Optional[int] = None, no_row_split: Optional[bool] = None):
+                   fused_mode: Optional[int] = None):
     """Set the library's test hooks (include/lsq_hip_debug.h) for the duration of a ``with`` block and restore the
     previous values afterwards, whatever happens inside.  Process-wide: meant for single-threaded tests and scripts."""
     handle = lib()
@@ -584,8 +584,6 @@ def debug_switches(xnor_popcount: Optional[bool] = None, force_streaming: Option
             old['lsq_debug_force_streaming'] = handle.lsq_debug_force_streaming(int(bool(force_streaming)))
         if fused_mode is not None:
             old['lsq_debug_fused_mode'] = handle.lsq_debug_fused_mode(int(fused_mode))
-        if no_row_split is not None:
-            old['lsq_debug_no_row_split'] = handle.lsq_debug_no_row_split(int(bool(no_row_split)))
         yield
     finally:
         for name, value in old.items():

@@ -47,18 +47,18 @@ def test_every_exported_symbol_is_declared_in_a_header(hip):
         pytest.skip('no nm on this machine')
     out = subprocess.run([nm, '-D', '--defined-only', hip.library_path()], capture_output=True, text=True, check=True).stdout
     exported = sorted({line.split()[-1] for line in out.splitlines() if ' T ' in line and line.split()[-1].startswith('lsq_')})
-    assert declared_functions(DEBUG_HEADER) == ['lsq_debug_force_streaming', 'lsq_debug_fused_mode', 'lsq_debug_no_row_split', 'lsq_debug_solver_trace', 'lsq_debug_xnor_impl']
+    assert declared_functions(DEBUG_HEADER) == ['lsq_debug_force_streaming', 'lsq_debug_fused_mode', 'lsq_debug_solver_trace', 'lsq_debug_xnor_impl']
     assert exported == sorted(declared_functions() + declared_functions(DEBUG_HEADER)), exported
 
 
 def test_debug_switches_restore_the_previous_values(hip):
     lib = hip.lib()
-    assert lib.lsq_debug_xnor_impl(0) == 0 and lib.lsq_debug_force_streaming(0) == 0 and lib.lsq_debug_fused_mode(0) == 0 and lib.lsq_debug_no_row_split(1) == 1
+    assert lib.lsq_debug_xnor_impl(0) == 0 and lib.lsq_debug_force_streaming(0) == 0 and lib.lsq_debug_fused_mode(0) == 0
     with pytest.raises(RuntimeError):
         with hip.debug_switches(xnor_popcount=True, force_streaming=True, fused_mode=2):
             assert lib.lsq_debug_xnor_impl(1) == 1 and lib.lsq_debug_fused_mode(2) == 2
             raise RuntimeError('a failing test body')
-    assert lib.lsq_debug_xnor_impl(0) == 0 and lib.lsq_debug_force_streaming(0) == 0 and lib.lsq_debug_fused_mode(0) == 0 and lib.lsq_debug_no_row_split(1) == 1
+    assert lib.lsq_debug_xnor_impl(0) == 0 and lib.lsq_debug_force_streaming(0) == 0 and lib.lsq_debug_fused_mode(0) == 0
 
 
 def test_library_exports_every_declared_symbol(hip):

@@ -389,8 +389,8 @@ def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
         # a workspace full of garbage (a caller's recycled scratch, the leftovers of an aborted launch): the arrival slots
         # are tagged with a per-launch epoch, so every scale is still written, and written right (round 4)
         junk = torch.randint(0, 256, (lib.lsq_sweep_workspace_bytes(n),), dtype=torch.uint8, device=DEV)
-        rw = lib.lsq_sweep_workspace_bytes(1) // 8                            # 64-bit words per row record; the last two are slots
-        junk.view(torch.int64)[rw - 2::rw] = 0x7fffffff00000003               # a plausible stale (epoch, arrivals) pair
+        rw = lib.lsq_sweep_workspace_bytes(1) // 8                            # 64-bit words per row record; the last one is the slot
+        junk.view(torch.int64)[rw - 1::rw] = 0x7fffffff00000003               # a plausible stale (epoch, arrivals) pair
         p3, s3 = call(junk)
         p4, s4 = call(junk)
         assert torch.equal(p3, p0) and torch.equal(s3, s0) and torch.equal(p4, p0) and torch.equal(s4, s0)
@@ -405,7 +405,7 @@ def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
         torch.cuda.synchronize()
         assert torch.equal(sc1.cpu()[:, 0], s1[:, 0]), (ci, sc1, s1[:, 0])
         rb = lib.lsq_sweep_workspace_bytes(1)
-        slots = ws.view(-1, rb)[:, rb - 16:rb - 8].contiguous().view(torch.int64).cpu()       # (epoch << 32 | arrivals) per row
+        slots = ws.view(-1, rb)[:, rb - 8:].contiguous().view(torch.int64).cpu()       # (epoch << 32 | arrivals) per row
         assert int(ws.sum()) == 0 or bool(((slots & 0xffffffff) <= 8).all() and ((slots >> 32) != 0).all())
 
 

@@ -338,49 +338,3 @@ def test_fused_small_image_path_is_taken_and_refuses_what_it_does_not_cover():
     assert lib.lsq_ls1_conv2d(None, ctypes.byref(g), 2.0, None, None, wb.data_ptr(), wsum.data_ptr(), 1, wsc.data_ptr(), None, 0,
                               None, None, None, y.data_ptr(), sc.data_ptr(), None) == -1
     torch.cuda.synchronize()
-
-
-# ------------------------------------------------------------------------------------------------ small batches: rows shared by workgroups
-def _quant(x, scheme, alpha, pre=None):
-    hip = _hip()
-    n, c, h, w = x.shape
-    geom = hip.make_geom(n, c, h, w, c, 3, 3, (1, 1), (1, 1), (1, 1), 1)
-    planes = torch.zeros((2 * hip.act_plane_words(geom),), dtype=torch.int64, device=DEV)
-    scales = torch.empty((2, n), dtype=torch.float32, device=DEV)
-    hip.act_quant(x, geom, scheme, 2, 3, alpha, planes, scales, None, pre)
-    torch.cuda.synchronize()
-    return planes.view(2, n, -1).clone(), scales.clone()
-
-
-@pytest.mark.parametrize('scheme', [2, 3])
-@pytest.mark.parametrize('c,h', [(64, 56), (128, 28), (256, 14), (512, 7), (64, 10), (192, 9)])
-def test_solver_schemes_with_rows_shared_by_several_workgroups(scheme, c, h):
-    """ls-2 / ls-T at small batch (activation_quantization.py:100: re-solved per batch at ANY batch size): up to 64 rows
-    CAN take the row-split sweeps (opt-in hook; measured slower than the single-launch kernel, so not the default) --
-    partial level-1 histograms merged by the last workgroup to arrive, plane 2 and the second scale by a split sweep --
-    instead of one workgroup per row.  Scales (v1 = the exact oracle's, v2 exact sums) and planes are bit-identical to the
-    single-launch kernel's, whatever the batch a sample came in and whichever path computed them."""
-    hip = _hip()
-    g = torch.Generator().manual_seed(1000 * c + h)
-    xs = (torch.randn(70, c, h, h, generator=g) * 1.3).to(DEV)
-    bn = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV)
-    for pre in (None, bn):
-        with hip.debug_switches(no_row_split=True):
-            p_ref, s_ref = _quant(xs, scheme, 3.0, pre)                  # 70 rows, the single-launch kernel
-        for n in (1, 3, 8, 33, 64):
-            with hip.debug_switches(no_row_split=False):
-                p, s = _quant(xs[:n].contiguous(), scheme, 3.0, pre)     # split path
-            assert torch.equal(s, s_ref[:, :n]), (c, h, n, (s - s_ref[:, :n]).abs().max())
-            assert torch.equal(p, p_ref[:, :n]), (c, h, n)
-            with hip.debug_switches(no_row_split=True):
-                p1, s1 = _quant(xs[:n].contiguous(), scheme, 3.0, pre)
-            assert torch.equal(s1, s) and torch.equal(p1, p)
-    xc = xs[:3].cpu().clamp(-3, 3)
-    _, s = _quant(xs[:3].contiguous(), scheme, 3.0)
-    assert np.array_equal(s[0].cpu().numpy(), E.solve_rows(xc.numpy(), scheme == 3, 3))
-    # without a clamp the second scale has no exact sum: such calls are never split (same result as before, any batch)
-    with hip.debug_switches(no_row_split=False):
-        _, s_a = _quant(xs[:4].contiguous(), scheme, -1.0)
-    with hip.debug_switches(no_row_split=True):
-        _, s_b = _quant(xs[:4].contiguous(), scheme, -1.0)
-    assert torch.equal(s_a, s_b)
