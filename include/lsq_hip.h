@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 9
+#define LSQ_ABI_VERSION 10
 
 /* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
 #define LSQ_ACT_NONE 0
@@ -104,8 +104,9 @@ int64_t lsq_weight_plane_words(const lsq_conv_geom* g);
  *   scales       out, [k][N] fp32: v1..vk per sample (LST: row 1 repeats v1)
  *   workspace    LS2 / LST without forced scales: lsq_solver_workspace_bytes(N) bytes, 8-byte aligned (required).
  *                LS1 / GF without forced scales: NULL, or lsq_sweep_workspace_bytes(N) bytes, 8-byte aligned, one
- *                buffer per stream, ANY content (the arrival slots are tagged with a per-launch epoch, so neither
- *                zero-filling nor the leftovers of an aborted launch matter): with it a row may be shared by several
+ *                buffer per stream, ANY content (the arrival slots are tagged with a per-launch epoch and released by
+ *                the last arrival, so neither zero-filling, the leftovers of an aborted launch nor the replay of a
+ *                captured launch matter): with it a row may be shared by several
  *                workgroups when the batch alone would leave CUs idle -- same planes, the scale is the same
  *                fixed-order sum either way.
  */
@@ -133,19 +134,32 @@ int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternar
                    size_t workspace_bytes, void* stream);
 
 /*
- * QuantConv2d.forward with 1-bit (LS1) activations on SMALL images in one launch (ABI v9): quantizer_ls_1
- * (quantization.py:35-56) and F.conv2d (binary_conv.py:165-173) fused -- the activation scale v1[n] = mean|clamp(x[n])|
- * only enters the epilogue, so one workgroup per sample (and out-channel slice) packs the sign plane into LDS, reduces
- * the row sum and convolves from LDS; no plane or scale round trip through memory (cifar100_ls1_kd.yaml: 32 launches of
- * the two-kernel path become 16).  Arguments as lsq_act_quant (x, g, clamp_alpha, pre_scale / pre_shift) and
- * lsq_xnor_conv2d (weight planes, epilogue); scales [1][N] out.  Results are bit-identical to lsq_act_quant(LS1) +
- * lsq_xnor_conv2d.  Covered: groups 1, dilation 1, kernels up to 3x3, C a multiple of 64 up to 512, H*W a multiple
- * of 4 up to 1024, clamp_alpha > 0, x 16-byte aligned; otherwise LSQ_E_UNSUPPORTED (take the two entry points).
+ * Chains of 1-bit (LS1) layers (ABI v10): lsq_xnor_conv2d with the NEXT layer's quantizer in its epilogue and / or this
+ * layer's activation scale taken from what the previous layer's epilogue left -- the lsq_act_quant launch between two
+ * quantized convolutions and its read of the activation tensor disappear (QuantConv2d.forward, binary_conv.py:161-173,
+ * for x_quant = 'ls-1': quantizer_ls_1, quantization.py:35-56, is a sign and a mean).
+ *   next        NULL, or where the epilogue leaves the next layer's input: sign(clamp(y * pre_scale[o] + pre_shift[o]))
+ *               as plane words [N][O/64][Ho + 2 pad_h][Wo + 2 pad_w] (halo pre-zeroed by the caller, interior fully
+ *               written) and, ADDED to sum_units[N] (int64, zeroed by the caller before the launch), the row sums of
+ *               |clamp(.)| in units of 2^e, e = ceil(log2 clamp_alpha) - 31 -- the exact arithmetic of lsq_act_quant's
+ *               plain sweeps, so that float(sum_units * 2^e / (O Ho Wo)) IS the scale lsq_act_quant(LS1) would return
+ *   x_units     NULL (then xscales [1][N] as in lsq_xnor_conv2d), or the sum_units a previous call left for THIS layer's
+ *               input; x_alpha = this layer's clamp (> 0), which fixes the unit
+ * One activation plane; 3x3 kernels over 64 / 128 / 256 / 512 channels (the integer-MFMA kernel), O a multiple of 64 when
+ * next is given; LSQ_E_UNSUPPORTED otherwise (the caller takes lsq_act_quant + lsq_xnor_conv2d: same bits).
  */
-int lsq_ls1_conv2d(const float* x, const lsq_conv_geom* g, float clamp_alpha, const float* pre_scale,
-                   const float* pre_shift, const uint64_t* wbits, const int32_t* wsum, int kw_planes,
-                   const float* wscales, const float* bias, int act, const float* act_slope,
-                   const float* res_pre, const float* res_post, float* y, float* scales, void* stream);
+typedef struct {
+  uint64_t* planes;
+  int64_t* sum_units;
+  const float* pre_scale; /* [O] or NULL: eval-mode batch norm in front of the next quantizer, folded */
+  const float* pre_shift;
+  float clamp_alpha;      /* the next layer's symmetric clamp, > 0 */
+  int pad_h, pad_w;       /* the next layer's padding (halo of its plane) */
+} lsq_next_ls1;
+int lsq_xnor_conv2d_chain(const uint64_t* xplanes, const float* xscales, const int64_t* x_units, float x_alpha,
+                          const uint64_t* wbits, const int32_t* wsum, int kw_planes, const float* wscales,
+                          const float* bias, const lsq_conv_geom* g, int act, const float* act_slope,
+                          const float* res_pre, const float* res_post, const lsq_next_ls1* next, float* y, void* stream);
 
 /*
  * Training-side pieces of the quantizers (ABI v8).  Rows are samples (activations, M = C*H*W)

@@ -1630,6 +1630,9 @@ __global__ __launch_bounds__(kThreads) void aq_sweep_kernel(Args a, int q) {
         double t = 0.0;
         for (int p = 0; p < a.parts; ++p) t += __hip_atomic_load(&partial[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.scales[(long long)q * a.N + row] = (float)(t / (double)a.row_elems);
+        // the launch is done with this row: tag 0 (no launch carries it), so that a REPLAY of this very launch -- a HIP
+        // graph re-issues it with the same epoch argument -- starts its count afresh like any other launch
+        __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       a.scales[(long long)q * a.N + row] = (float)(tot / (double)a.row_elems);

@@ -25,6 +25,17 @@ struct ConvArgs {
   const float* res_pre;                // [N][O][Ho][Wo] or null
   const float* res_post;
   int dbg_no_corr;                     // tuning builds only
+  // ---- chained 1-bit layers (lsq_xnor_conv2d_chain): the NEXT layer's ls-1 quantizer in this layer's epilogue, and this
+  // layer's activation scale from the exact row sum the PREVIOUS layer's epilogue left
+  const long long* xunits;             // [N] or null: row sum of |clamp(x)| in units of 2^e; xscale = float(units * xunit / xM)
+  double xunit, xM;
+  unsigned* nq_planes32;               // or null: next layer's plane [N][O/64][nq_Hp][nq_Wp] as dwords
+  unsigned long long* nq_units;        // [N]: += this launch's part of the next layer's row sums (zeroed by the caller)
+  const float* nq_scale;               // [O] or null: folded batch norm in front of the next quantizer
+  const float* nq_shift;
+  float nq_alpha;                      // next layer's clamp (> 0)
+  double nq_magic, nq_inv_unit;        // 1.5 * 2^(52 + e) and 2^-e
+  int nq_Hp, nq_Wp, nq_ph, nq_pw;
   int tap_xoff[64];                    // (kh*dil_h)*Wp + kw*dil_w per tap
 };
 

@@ -250,12 +250,12 @@ using namespace lsq;
 static std::atomic<int> g_force_popcount{0};
 extern "C" int lsq_debug_xnor_impl(int popcount_only) { return g_force_popcount.exchange(popcount_only, std::memory_order_relaxed); }
 
-extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
-                               const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
-                               const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
-                               const float* res_post,
-                               float* y, void* stream) {
-  if (!xplanes || !xscales || !wbits || !wsum || !wscales || !y) return LSQ_E_NULL;
+static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
+                            const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
+                            const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
+                            const float* res_post, float* y, void* stream,
+                            const int64_t* x_units, float x_alpha, const lsq_next_ls1* next) {
+  if (!xplanes || (!xscales && !x_units) || !wbits || !wsum || !wscales || !y) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
   if (kx < 1 || kx > LSQ_MAX_PLANES || kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
   const int Ho = out_h(g), Wo = out_w(g);
@@ -283,6 +283,36 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
   a.slope = act_slope;
   a.res_pre = res_pre;
   a.res_post = res_post;
+  const bool chained = x_units != nullptr || next != nullptr;
+  if (chained) {
+    // chained 1-bit layers run on the integer-MFMA kernel only (3x3, C in {64, 128, 256, 512}); one activation plane
+    if (kx != 1) return LSQ_E_SCHEME;
+    if (x_units) {
+      if (!(x_alpha > 0.f)) return LSQ_E_UNSUPPORTED;
+      int e2 = 0;
+      (void)frexpf(x_alpha, &e2);
+      a.xunits = (const long long*)x_units;
+      a.xunit = ldexp(1.0, e2 - 31);
+      a.xM = (double)g->C * g->H * g->W;
+    }
+    if (next) {
+      if (!next->planes || !next->sum_units) return LSQ_E_NULL;
+      if ((next->pre_scale == nullptr) != (next->pre_shift == nullptr)) return LSQ_E_NULL;
+      if (!(next->clamp_alpha > 0.f) || g->O % 64 || next->pad_h < 0 || next->pad_w < 0) return LSQ_E_UNSUPPORTED;
+      int e2 = 0;
+      (void)frexpf(next->clamp_alpha, &e2);
+      a.nq_planes32 = (unsigned*)next->planes;
+      a.nq_units = (unsigned long long*)next->sum_units;
+      a.nq_scale = next->pre_scale;
+      a.nq_shift = next->pre_shift;
+      a.nq_alpha = next->clamp_alpha;
+      a.nq_magic = ldexp(1.5, 52 + e2 - 31);
+      a.nq_inv_unit = ldexp(1.0, 31 - e2);
+      a.nq_ph = next->pad_h; a.nq_pw = next->pad_w;
+      a.nq_Hp = Ho + 2 * next->pad_h; a.nq_Wp = Wo + 2 * next->pad_w;
+      if ((long long)g->N * (g->O / 64) * a.nq_Hp * a.nq_Wp >= (1ll << 30)) return LSQ_E_UNSUPPORTED;
+    }
+  }
   const long long wplane_words = lsq_weight_plane_words(g);
   const int taps = g->KH * g->KW;
   hipStream_t st = (hipStream_t)stream;
@@ -297,11 +327,31 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
       a.wscale = wscales + (long long)q * g->O;
       a.accumulate = first ? 0 : 1;
       a.final_pass = (q == kw_planes - 1 && p0 + np >= kx) ? 1 : 0;
-      int e = g_force_popcount.load(std::memory_order_relaxed) ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
+      int e = (g_force_popcount.load(std::memory_order_relaxed) && !chained) ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
+      if (e == kXnorMfmaNotEligible && chained) return LSQ_E_UNSUPPORTED;
       if (e == kXnorMfmaNotEligible) e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
       if (e) return e;
       first = false;
     }
   }
   return LSQ_OK;
+}
+
+extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
+                               const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
+                               const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
+                               const float* res_post,
+                               float* y, void* stream) {
+  return xnor_conv2d_impl(xplanes, kx, xscales, wbits, wsum, kw_planes, wscales, bias, g, relu, act_slope, res_pre, res_post, y,
+                          stream, nullptr, -1.f, nullptr);
+}
+
+extern "C" int lsq_xnor_conv2d_chain(const uint64_t* xplanes, const float* xscales, const int64_t* x_units, float x_alpha,
+                                     const uint64_t* wbits, const int32_t* wsum, int kw_planes, const float* wscales,
+                                     const float* bias, const lsq_conv_geom* g, int relu, const float* act_slope,
+                                     const float* res_pre, const float* res_post, const lsq_next_ls1* next, float* y,
+                                     void* stream) {
+  if (x_units && xscales) return LSQ_E_SCHEME;               // one source for the activation scale
+  return xnor_conv2d_impl(xplanes, 1, xscales, wbits, wsum, kw_planes, wscales, bias, g, relu, act_slope, res_pre, res_post, y,
+                          stream, x_units, x_alpha, next);
 }

@@ -41,7 +41,7 @@ constexpr unsigned kM0 = 0x01010101u;
 // once the epilogue inputs were requested early (fewer waves per SIMD).
 // NWAVES: waves per workgroup, all on the same 32 out-channels (8 when the fragments of 512 channels fill the LDS of
 // a CU: one workgroup per CU, still two waves per SIMD).
-template <int KX, int GG, int TAPS, int NWAVES, int WPC>
+template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN>
 __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
   constexpr int NT = 64 * NWAVES;
   constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (word, tap, half of the dword's bits)
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   // output instead of loops over kernel rows and columns.
   __shared__ __attribute__((aligned(16))) short s_fc[8][8][32];    // |.| <= taps * channels = 4608
   __shared__ __attribute__((aligned(16))) float s_scale[32], s_bias[32], s_slope[32];
+  __shared__ float s_nqs[CHAIN ? 32 : 1], s_nqt[CHAIN ? 32 : 1];      // chained layers: the next quantizer's folded batch norm
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int o0 = blockIdx.y * 32;
@@ -159,6 +160,10 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     s_scale[tid] = a.wscale[o0 + tid];
     s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
     s_slope[tid] = a.relu >= LSQ_ACT_PRELU ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o0 + tid] : 0.f;   // (0: ReLU)
+    if constexpr (CHAIN) {
+      s_nqs[tid] = (a.nq_planes32 && a.nq_scale) ? a.nq_scale[o0 + tid] : 1.f;
+      s_nqt[tid] = (a.nq_planes32 && a.nq_scale) ? a.nq_shift[o0 + tid] : 0.f;
+    }
   }
   __syncthreads();
   for (int i = tid; i < 8 * 8 * 32; i += NT) {
@@ -197,7 +202,9 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     const unsigned yoff = (unsigned)((ln * a.O + o0 + ob) * HoWo + cur.ho * a.Wo + cur.wo);
     float xs[KX], rv[16], basev[16];
 #pragma unroll
-    for (int p = 0; p < KX; ++p) xs[p] = a.xscales[p * a.N + ln] * 0.03125f;
+    for (int p = 0; p < KX; ++p) xs[p] = (!CHAIN || a.xscales) ? a.xscales[p * a.N + ln] * 0.03125f : 0.f;
+    if (CHAIN && a.xunits)          // chained ls-1 layer: the scale is the exact row sum the producer's epilogue left, / M as the sweeps do
+      xs[0] = (float)(((double)a.xunits[ln] * a.xunit) / a.xM) * 0.03125f;
     if (want_pre || want_post) {
       const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
 #pragma unroll
@@ -288,6 +295,11 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     }
 
     // ---- epilogue of this tile: the popcount kernel's arithmetic on the same integers -> the same floats --------
+    float nqv[CHAIN ? 16 : 1];                   // (chained layers: the tile's outputs, kept for the next layer's quantizer)
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) nqv[i] = 0.f;
+    }
     if (cur.n < a.N) {                           // (false only for the lanes past the last pixel)
       // float(acc) = 32 * (b * s) exactly (|.| < 2^18) and xs / 32 is exact, so (xs / 32) * float(acc) is the very
       // product xs * float(b * s) of the popcount kernel
@@ -324,6 +336,62 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff] = outv[i];
+      if constexpr (CHAIN) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nqv[i] = outv[i];
+      }
+    }
+    if (CHAIN && fin && a.nq_planes32) {         // (uniform; compiled into the one-plane kernels only)
+      // The NEXT layer's 1-bit quantizer (quantizer_ls_1 behind the block's batch norm and clamp, quantization.py:35-56)
+      // on the values this tile just produced: sign bits straight into the next plane -- this wave's 32 out-channels are
+      // one dword of the next layer's channel word --, and sum |x| in the exact arithmetic of the plain sweeps
+      // (lsq_act_quant.hip, EXACT): the fp32 sum of every octet of channels in channel order, rounded to a multiple of
+      // 2^e; such multiples add exactly, here as 64-bit integers in units of 2^e (atomics in any order give the same
+      // total).  A lane of half hh holds channels 4 hh + (i & 3) + 8 (i >> 2): octet g = registers 4 g .. 4 g + 3 of
+      // both halves; half 0 sums its four, half 1 continues the chain with its own.
+      const bool valid = cur.n < a.N;
+      unsigned mask = 0u;
+      double units = 0.0;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float av[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = 4 * g4 + k;
+          const int cl = ob + k + 8 * g4;                                    // channel inside the 32-channel tile
+          float t = valid ? nqv[CHAIN ? i : 0] : 0.f;
+          if (a.nq_scale) t = fmaf(t, s_nqs[CHAIN ? cl : 0], s_nqt[CHAIN ? cl : 0]);
+          t = fminf(fmaxf(t, -a.nq_alpha), a.nq_alpha);
+          mask |= (t >= 0.f ? 1u : 0u) << (ob + k + 8 * g4);
+          av[k] = fabsf(t);
+        }
+        const float lo4 = ((av[0] + av[1]) + av[2]) + av[3];                  // channels 8 g .. 8 g + 3 (half 0)
+        // (v_permlane32_swap: the upper 32 lanes receive the lower 32 lanes' value -- one VALU instruction where a
+        //  shuffle is an LDS round trip)
+        const float from0 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(lo4), __float_as_uint(lo4), false, false)[0]);
+        const float oct = (((from0 + av[0]) + av[1]) + av[2]) + av[3];        // half 1: ... + channels 8 g + 4 .. 8 g + 7
+        const double r = ((double)oct + a.nq_magic) - a.nq_magic;
+        units += (hh == 1 && valid) ? r * a.nq_inv_unit : 0.0;                // an integer below 2^53
+      }
+      mask |= __builtin_amdgcn_permlane32_swap(mask, mask, false, false)[1];   // lower lanes: | the upper lanes' bits
+      if (valid && hh == 0) {
+        const int j = o0 >> 6, half = (o0 >> 5) & 1;
+        a.nq_planes32[2u * (unsigned)(((cur.n * (a.O >> 6) + j) * a.nq_Hp + cur.ho + a.nq_ph) * a.nq_Wp + cur.wo + a.nq_pw) + (unsigned)half] = mask;
+      }
+      // one atomic per wave and sample of the tile (small images: a tile of 32 pixels spans two samples): the lanes of
+      // the first remaining sample are summed with DPP shifts (fp64 holds these integers exactly), then the next sample
+      bool todo = valid && hh == 1;
+      while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+        const int lead = __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo));
+        const int n_cur = __builtin_amdgcn_readlane(cur.n, lead);
+        const bool mine = todo && cur.n == n_cur;
+        const double tot = wave_incl_scan(mine ? units : 0.0);
+        const unsigned long long total = (unsigned long long)__longlong_as_double(
+            ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(tot) >> 32), 63) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)__double_as_longlong(tot), 63));
+        if (lane == 0) atomicAdd(&a.nq_units[n_cur], total);
+        todo = todo && !mine;
+      }
     }
 
     if (!more) break;
@@ -346,7 +414,10 @@ int launch(const ConvArgs& a, hipStream_t st) {
   long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
   if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
-  hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  if (KX == 1 && (a.xunits || a.nq_planes32))
+    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  else
+    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
 }
 

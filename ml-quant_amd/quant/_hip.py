@@ -18,7 +18,7 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -34,6 +34,14 @@ class ConvGeom(ctypes.Structure):
 
     def key(self):
         return tuple(getattr(self, n) for n, _ in self._fields_)
+
+
+class NextLs1(ctypes.Structure):
+    """Mirror of ``lsq_next_ls1``: where a chained convolution leaves the next layer's 1-bit input."""
+
+    _fields_ = [('planes', ctypes.c_void_p), ('sum_units', ctypes.c_void_p), ('pre_scale', ctypes.c_void_p),
+                ('pre_shift', ctypes.c_void_p), ('clamp_alpha', ctypes.c_float), ('pad_h', ctypes.c_int32),
+                ('pad_w', ctypes.c_int32)]
 
 
 class LsqHipError(RuntimeError):
@@ -79,8 +87,8 @@ def _declare(lib):
     for hook in ('lsq_debug_xnor_impl', 'lsq_debug_force_streaming', 'lsq_debug_fused_mode'):     # include/lsq_hip_debug.h
         getattr(lib, hook).restype = i32
         getattr(lib, hook).argtypes = [i32]
-    lib.lsq_ls1_conv2d.restype = i32
-    lib.lsq_ls1_conv2d.argtypes = [vp, gp, f32, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.lsq_xnor_conv2d_chain.restype = i32
+    lib.lsq_xnor_conv2d_chain.argtypes = [vp, vp, vp, f32, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, ctypes.POINTER(NextLs1), vp, vp]
     lib.lsq_quant_values.restype = i32
     lib.lsq_quant_values.argtypes = [vp, i64, i64, i32, vp, f32, vp, vp]
     lib.lsq_ste_backward.restype = i32
@@ -136,12 +144,23 @@ def check(code: int, what: str) -> None:
 
 def stream_ptr(device=None) -> int:
     """HIP stream the kernels of ``device`` are launched on (torch's current stream of THAT device)."""
+    if _raw_stream is not None:               # (no Stream object built per launch: this runs several times per layer)
+        d = torch.device(device) if device is not None else None
+        return _raw_stream(torch.cuda.current_device() if d is None or d.index is None else d.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+_SAME_DEVICE = contextlib.nullcontext()
 
 
 def _on(t: torch.Tensor):
     """Device guard for a C-ABI call: the library never calls hipSetDevice, so the tensor's device is made
     current around the launch (a model on cuda:1 with cuda:0 current must not launch on cuda:0's stream)."""
+    if t.device.index == torch.cuda.current_device():
+        return _SAME_DEVICE                    # (the common case: entering torch.cuda.device costs microseconds per launch)
     return torch.cuda.device(t.device)
 
 
@@ -228,14 +247,27 @@ def _remember(cache: dict, key, buf):
         cache.pop(next(iter(cache)))
 
 
+_ws_bytes_memo = {}
+
+
+def _ws_bytes(fn: str, rows: int) -> int:
+    key = (fn, rows)
+    need = _ws_bytes_memo.get(key)
+    if need is None:
+        if len(_ws_bytes_memo) > 256:
+            _ws_bytes_memo.clear()
+        need = _ws_bytes_memo[key] = getattr(lib(), fn)(rows)
+    return need
+
+
 def solver_workspace(rows: int, device) -> torch.Tensor:
     """Scratch for the LS2/LST solve (slot records passed from the sweep to the solve kernel); cached per
     device and grown on demand -- kernels of one stream run in order, so sharing it is safe."""
-    need = lib().lsq_solver_workspace_bytes(rows)
+    need = _ws_bytes('lsq_solver_workspace_bytes', rows)
     device = torch.device(device)
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, stream_ptr(device))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.empty((need,), dtype=torch.uint8, device=device)
@@ -248,11 +280,11 @@ _sweep_ws_cache = {}
 def sweep_workspace(rows: int, device) -> torch.Tensor:
     """Row workspace of the ls-1 / gf-k sweeps (partial sums + arrival counters of rows shared by several workgroups):
     any content (the arrival slots carry a per-launch epoch); cached per (device, stream) like the solver's."""
-    need = lib().lsq_sweep_workspace_bytes(rows)
+    need = _ws_bytes('lsq_sweep_workspace_bytes', rows)
     device = torch.device(device)
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, stream_ptr(device))
     buf = _sweep_ws_cache.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.zeros((need,), dtype=torch.uint8, device=device)
@@ -349,27 +381,29 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
 E_UNSUPPORTED = -6
 
 
-def ls1_conv2d(x: torch.Tensor, alpha: float, wbits: torch.Tensor, wsum: torch.Tensor, wscales: torch.Tensor,
-               bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor, scales: torch.Tensor, pre: Optional[tuple] = None,
-               relu: bool = False, res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
-               prelu: Optional[torch.Tensor] = None) -> bool:
-    """ls-1 quantizer + XNOR convolution in ONE launch for small images (lsq_ls1_conv2d); ``scales`` [1, N] receives the
-    activation scales.  Returns False -- nothing launched -- when the geometry is not covered (the caller then takes
-    act_quant + xnor_conv2d, which give the same bits)."""
-    x = _f32c(x)
+def xnor_conv2d_chain(planes: torch.Tensor, xscales: Optional[torch.Tensor], x_units: Optional[torch.Tensor], x_alpha: float,
+                      wbits: torch.Tensor, wsum: torch.Tensor, wscales: torch.Tensor, bias: Optional[torch.Tensor],
+                      geom: ConvGeom, y: torch.Tensor, relu: bool = False, res_pre: Optional[torch.Tensor] = None,
+                      res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None,
+                      nxt: Optional[NextLs1] = None) -> bool:
+    """lsq_xnor_conv2d for a CHAIN of 1-bit layers: the activation scale from the row sums ``x_units`` a previous call's
+    epilogue left (or ``xscales`` [1, N]), and / or the next layer's quantizer in this call's epilogue (``nxt``).  Returns
+    False -- nothing launched -- when the geometry is outside the integer-MFMA kernel (the caller takes the unchained
+    calls: same bits)."""
     act, slope = _act(relu, prelu, geom.O)
     m = geom.C * geom.H * geom.W
     nres = (res_pre is not None) + (res_post is not None)
     macs = y.numel() * geom.C * geom.KH * geom.KW * wscales.shape[0]
-    with _on(x), _Timed('lsq_ls1_conv2d', 4 * geom.N * m + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
-                         4 * geom.N * m + 4 * y.numel()):
-        code = lib().lsq_ls1_conv2d(x.data_ptr(), ctypes.byref(geom), float(alpha), None if pre is None else pre[0].data_ptr(),
-                                    None if pre is None else pre[1].data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
-                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), act, ptr(slope), ptr(res_pre), ptr(res_post),
-                                    y.data_ptr(), scales.data_ptr(), stream_ptr(x.device))
+    extra = 0 if nxt is None else y.numel() // 8
+    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * m // 8 + 4 * y.numel() * (1 + nres) + extra, macs,
+                         f'C{geom.C}_H{geom.H}_s{geom.stride_h}', geom.N * m // 8 + 4 * y.numel()):
+        code = lib().lsq_xnor_conv2d_chain(planes.data_ptr(), ptr(xscales), ptr(x_units), float(x_alpha), wbits.data_ptr(),
+                                           wsum.data_ptr(), wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom),
+                                           act, ptr(slope), ptr(res_pre), ptr(res_post),
+                                           None if nxt is None else ctypes.byref(nxt), y.data_ptr(), stream_ptr(y.device))
     if code == E_UNSUPPORTED:
         return False
-    check(code, 'lsq_ls1_conv2d')
+    check(code, 'lsq_xnor_conv2d_chain')
     return True
 
 

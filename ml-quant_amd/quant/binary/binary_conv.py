@@ -99,10 +99,6 @@ class QuantConv2d(nn.Conv2d):
         raise ValueError(f'{kind} is not a valid clamping function.')
 
     # ------------------------------------------------------------------ forward
-    #: ls-1 activations on images of at most 1024 pixels, eager launches: one fused quantize + convolve launch (False:
-    #: always the two kernels)
-    fuse_small = True
-
     #: train-mode CUDA tensors through the kernels (False: the torch formulation, e.g. to compare the two in tests)
     hip_train = True
 
@@ -190,14 +186,16 @@ class QuantConv2d(nn.Conv2d):
 
     def fused_forward(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
                       res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
-                      prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None) -> torch.Tensor:
         """``act(self(pre_bn(x)) + res_pre) + res_post`` -- one residual-block half (quant/models/resnet.py:
         95-100, 182-190); ``act`` = ReLU (``relu=True``), PReLU (``prelu`` = the nn.PReLU weight) or identity.
         On the HIP path the eval-mode batch norm is folded into the quantizer's read and the non-linearity /
         shortcut additions into the convolution's epilogue, so none of them is a separate pass over HBM;
         elsewhere it is the plain composition of the modules."""
         if self._wants_hip(x) and (pre_bn is None or (not pre_bn.training and pre_bn.track_running_stats)):
-            return self._forward_hip(x, pre_bn, relu, res_pre, res_post, prelu)
+            # next_q = (batch norm or None, QuantConv2d) that will consume the result: with 1-bit activations on both
+            # sides the consumer's quantizer runs in THIS convolution's epilogue (quant.binary.chain)
+            return self._forward_hip(x, pre_bn, relu, res_pre, res_post, prelu, next_q)
         y = self(x if pre_bn is None else pre_bn(x))
         if res_pre is not None:
             y = y + res_pre
@@ -209,8 +207,13 @@ class QuantConv2d(nn.Conv2d):
 
     def _folded_bn(self, bn: nn.BatchNorm2d):
         """(scale, shift) with bn(x) = x * scale + shift in eval mode; cached on the BN's buffer versions."""
-        tensors = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
-        stamp = (id(bn), bn.eps) + tuple((t._version, t.data_ptr()) for t in tensors)
+        # (read straight from the module's dicts: nn.Module.__getattr__ costs more than the rest of this check)
+        b, p = bn._buffers, bn._parameters
+        mean, var = b['running_mean'], b['running_var']
+        stamp = (id(bn), bn.eps, mean._version, mean.data_ptr(), var._version, var.data_ptr())
+        if bn.affine:
+            gw, gb = p['weight'], p['bias']
+            stamp += (gw._version, gw.data_ptr(), gb._version, gb.data_ptr())
         hit = self._hip_cache.get('bn')
         if hit is None or hit[0] != stamp:
             with torch.no_grad():
@@ -221,10 +224,69 @@ class QuantConv2d(nn.Conv2d):
             self._hip_cache['bn'] = hit
         return hit[1], hit[2]
 
+    def _chain_target(self, next_q, n: int, ho: int, wo: int, device, _hip):
+        """``lsq_next_ls1`` for the consumer ``next_q = (bn, conv)`` of this layer's output, or None when the pair cannot
+        be chained (other schemes, moving-average scales, no clamp, channel counts)."""
+        from quant.binary import chain
+        if next_q is None or not chain.ENABLED or self.x_quant != 'ls-1' or self.out_channels % 64:
+            return None
+        if n * self.out_channels * ho * wo > chain.MAX_ELEMENTS:    # (large layers: the separate HBM-bound sweep is cheaper)
+            return None
+        bn, conv = next_q
+        if not isinstance(conv, QuantConv2d) or conv.x_quant != 'ls-1' or conv.training or conv.w_quant == 'fp':
+            return None
+        if conv.in_channels != self.out_channels or conv.groups != 1 or isinstance(conv.padding, str) or conv.padding_mode != 'zeros':
+            return None
+        if conv._alpha() <= 0 or conv.x_approximate.eval_scales(n) is not None:
+            return None
+        if bn is not None and (bn.training or not bn.track_running_stats):
+            return None
+        pre = None if bn is None else conv._folded_bn(bn)
+        ph, pw = conv.padding
+        key = ('pre', n, self.out_channels, ho, wo, ph, pw, device, _hip.stream_ptr(device))
+        planes = conv._hip_cache.get(key)
+        if planes is None:
+            words = n * (self.out_channels // 64) * (ho + 2 * ph) * (wo + 2 * pw)
+            planes = torch.zeros((words,), dtype=torch.int64, device=device)          # zero halo; the interior is rewritten
+            stale = [kk for kk in list(conv._hip_cache) if isinstance(kk, tuple) and kk[0] == 'pre']
+            for kk in stale[:max(0, len(stale) - 3)]:
+                conv._hip_cache.pop(kk, None)
+            conv._hip_cache[key] = planes
+        units = chain.accumulator(n, device)
+        nxt = _hip.NextLs1(planes.data_ptr(), units.data_ptr(), None if pre is None else pre[0].data_ptr(),
+                           None if pre is None else pre[1].data_ptr(), conv._alpha(), ph, pw)
+        keep = (planes, units, pre)
+        return nxt, chain.PreQuant(conv, bn, planes, units, (n, self.out_channels, ho, wo), _hip.stream_ptr(device)), keep
+
+    def _act_planes(self, x, geom, k, n, pre, xq, _hip):
+        """Quantize ``x`` with lsq_act_quant into this module's plane workspace; returns (planes, scales)."""
+        # (one workspace per launch stream: two streams through one module must not share planes and scales)
+        key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device,
+               _hip.stream_ptr(x.device))
+        ws = self._hip_cache.get(key)
+        if ws is None:
+            words = _hip.act_plane_words(geom)
+            # halo words must be zero; the kernels only ever write the interior
+            ws = (torch.zeros((k * words,), dtype=torch.int64, device=x.device),
+                  torch.empty((k, n), dtype=torch.float32, device=x.device))
+            # one plane workspace per input shape; serving with many batch sizes must not grow without bound
+            stale = [kk for kk in list(self._hip_cache) if isinstance(kk, tuple) and kk[0] == 'act']
+            for kk in stale[:max(0, len(stale) - 3)]:
+                self._hip_cache.pop(kk, None)
+            self._hip_cache[key] = ws
+        planes, scales = ws
+        forced = xq.eval_scales(n)
+        if forced is not None:
+            forced = forced.to(device=x.device, dtype=torch.float32).contiguous()
+        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced, pre)
+        return planes, scales
+
     def _forward_hip(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
                      res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
-                     prelu: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None) -> torch.Tensor:
         from quant import _hip
+        from quant.binary import chain
+        handed = chain.pending(x)                  # (an attribute of the tensor object: read before detach())
         x = x.detach()
         pre = None if pre_bn is None else self._folded_bn(pre_bn)
         res_pre = None if res_pre is None else res_pre.detach().contiguous()
@@ -242,36 +304,32 @@ class QuantConv2d(nn.Conv2d):
             return y
         xq = self.x_approximate
         k = xq.n_planes
-        if (self.x_quant == 'ls-1' and self.fuse_small and xq.eval_scales(n) is None and h * w <= 1024
-                and not torch.cuda.is_current_stream_capturing()):
-            # small images (CIFAR), eager launches: quantizer and convolution in ONE launch, no plane round trip
-            # (csrc/lsq_ls1_fused.hip) -- the forward is host-bound there and half the launches are worth more than the
-            # kernels' speed (measured: 94 k -> 116 k images/s eager at batch 100); under graph capture the host does not
-            # matter and the two specialised kernels are faster (181 k against 115 k images/s), so a capture takes those.
-            # Same bits either way.
-            scales = torch.empty((1, n), dtype=torch.float32, device=x.device)
-            if _hip.ls1_conv2d(x, self._alpha(), wbits, wsum, wscales, bias, geom, y, scales, pre, relu, res_pre, res_post, prelu):
-                self.last_act_scales = scales
-                return y
-        # (one workspace per launch stream: two streams through one module must not share planes and scales)
-        key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device,
-               torch.cuda.current_stream(x.device).cuda_stream)
-        ws = self._hip_cache.get(key)
-        if ws is None:
-            words = _hip.act_plane_words(geom)
-            # halo words must be zero; the kernels only ever write the interior
-            ws = (torch.zeros((k * words,), dtype=torch.int64, device=x.device),
-                  torch.empty((k, n), dtype=torch.float32, device=x.device))
-            # one plane workspace per input shape; serving with many batch sizes must not grow without bound
-            stale = [kk for kk in list(self._hip_cache) if isinstance(kk, tuple) and kk[0] == 'act']
-            for kk in stale[:max(0, len(stale) - 3)]:
-                self._hip_cache.pop(kk, None)
-            self._hip_cache[key] = ws
-        planes, scales = ws
-        forced = xq.eval_scales(n)
-        if forced is not None:
-            forced = forced.to(device=x.device, dtype=torch.float32).contiguous()
-        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced, pre)
+        if self.x_quant == 'ls-1' and chain.ENABLED:
+            # chained 1-bit layers: take the planes and row sums the producer's epilogue left for THIS call, and / or leave
+            # the consumer's in this call's epilogue
+            stream = _hip.stream_ptr(x.device)
+            if not (handed is not None and handed.consumer is self and handed.pre_bn is pre_bn and handed.stream == stream
+                    and handed.shape == tuple(x.shape) and xq.eval_scales(n) is None and self._alpha() > 0):
+                handed = None
+            target = self._chain_target(next_q, n, ho, wo, x.device, _hip)
+            if handed is not None or target is not None:
+                planes_in, scales_in, units_in = None, None, None
+                if handed is not None:
+                    planes_in, units_in = handed.planes, handed.units
+                else:
+                    planes_in, scales_in = self._act_planes(x, geom, k, n, pre, xq, _hip)
+                if _hip.xnor_conv2d_chain(planes_in, scales_in, units_in, self._alpha(), wbits, wsum, wscales, bias, geom, y,
+                                          relu, res_pre, res_post, prelu, None if target is None else target[0]):
+                    self.last_act_scales = scales_in          # (None when the scale came from the producer's row sums)
+                    if target is not None:
+                        y._lsq_pre = target[1]
+                        y._lsq_keep = target[2]
+                    return y
+                if handed is None and scales_in is not None:   # outside the matrix-core kernel: the plain call, same planes
+                    _hip.xnor_conv2d(planes_in, k, scales_in, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)
+                    self.last_act_scales = scales_in
+                    return y
+        planes, scales = self._act_planes(x, geom, k, n, pre, xq, _hip)
         _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)
         self.last_act_scales = scales
         return y

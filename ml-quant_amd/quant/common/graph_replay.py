@@ -46,7 +46,8 @@ class GraphedForward:
         # whatever the modules' and the binding's caches evict later
         from quant import _hip
         key = (self.static_input.device.index, self.stream.cuda_stream)
-        self._keepalive = [_hip._ws_cache.get(key), _hip._sweep_ws_cache.get(key)]
+        from quant.binary import chain
+        self._keepalive = [_hip._ws_cache.get(key), _hip._sweep_ws_cache.get(key), chain._arenas.get(key)]
         for m in self.model.modules():
             cache = getattr(m, '_hip_cache', None)
             if isinstance(cache, dict):

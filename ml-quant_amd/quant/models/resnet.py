@@ -219,11 +219,14 @@ class XnorBasicBlock(nn.Module):
             # kernel pair (QuantConv2d.fused_forward); same arithmetic as the modular path below
             sc = self.shortcut(x)
             a1, a2 = _act_args(self.nonlin1), _act_args(self.nonlin2)
+            # next_q: who quantizes the result next -- with 1-bit activations that quantizer runs in the producing
+            # convolution's epilogue (quant.binary.chain); `chain_next` = the following block's (bn1, conv1), set by QResNet
+            nxt = self.__dict__.get('chain_next')
             if self.double_shortcut:
-                first = self.conv1.fused_forward(x, self.bn1, res_post=sc, **a1)
-                return self.conv2.fused_forward(first, self.bn2, res_post=first, **a2)
-            first = self.conv1.fused_forward(x, self.bn1, **a1)
-            return self.conv2.fused_forward(first, self.bn2, res_pre=sc, **a2)
+                first = self.conv1.fused_forward(x, self.bn1, res_post=sc, next_q=(self.bn2, self.conv2), **a1)
+                return self.conv2.fused_forward(first, self.bn2, res_post=first, next_q=nxt, **a2)
+            first = self.conv1.fused_forward(x, self.bn1, next_q=(self.bn2, self.conv2), **a1)
+            return self.conv2.fused_forward(first, self.bn2, res_pre=sc, next_q=nxt, **a2)
         first = self.nonlin1(self.conv1(self.bn1(x)))
         if self.double_shortcut:
             first = first + self.shortcut(x)
@@ -297,6 +300,11 @@ class QResNet(nn.Module):
                                       moving_average_mode, moving_average_momentum)
         self.linear_classifier = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(),
                                                nn.Linear(planes, output_classes))
+        # every xnor block knows the block behind it (a plain attribute, not a sub-module): its last convolution can then
+        # prepare that block's first quantized input (quant.binary.chain)
+        for cur, nxt in zip(self.blocks[1:], self.blocks[2:]):
+            if isinstance(cur, XnorBasicBlock) and isinstance(nxt, XnorBasicBlock):
+                cur.__dict__['chain_next'] = (nxt.bn1, nxt.conv1)
 
     def _make_layer(self, block, layer_config: dict, in_planes: int, out_planes: int, num_blocks: int,
                     nonlins: List[str], stride: int, moving_average_mode: str = 'off',
@@ -310,6 +318,12 @@ class QResNet(nn.Module):
         return in_planes
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.training and x.is_cuda:
+            from quant.binary import chain
+            with chain.scope(x.device):            # (the row-sum accumulators of chained 1-bit layers: one fill per forward)
+                for stage in self.blocks:
+                    x = stage(x)
+            return self.linear_classifier(x)
         for stage in self.blocks:
             x = stage(x)
         return self.linear_classifier(x)

@@ -405,8 +405,10 @@ def test_sweeps_with_rows_shared_by_several_workgroups(scheme, k):
         torch.cuda.synchronize()
         assert torch.equal(sc1.cpu()[:, 0], s1[:, 0]), (ci, sc1, s1[:, 0])
         rb = lib.lsq_sweep_workspace_bytes(1)
-        slots = ws.view(-1, rb)[:, rb - 8:].contiguous().view(torch.int64).cpu()       # (epoch << 32 | arrivals) per row
-        assert int(ws.sum()) == 0 or bool(((slots & 0xffffffff) <= 8).all() and ((slots >> 32) != 0).all())
+        # (epoch << 32 | arrivals) per row while a launch runs; the last arrival leaves tag 0, so that a HIP graph replaying
+        # ONE captured launch -- same epoch argument every time -- counts afresh (test_graph_replay_equals_eager_forward)
+        slots = ws.view(-1, rb)[:, rb - 8:].contiguous().view(torch.int64).cpu()
+        assert bool((slots == 0).all())
 
 
 def test_greedy_two_bit_single_launch_kernel():

@@ -266,75 +266,73 @@ def test_training_loop_on_the_gpu_takes_the_kernels():
     assert losses[True][0] == pytest.approx(losses[False][0], rel=2e-2)      # (a binarized net amplifies fp32 reassociation)
 
 
-# ------------------------------------------------------------------------------------------------ small images: one launch per layer
-@pytest.mark.parametrize('c,h,o,stride,ws', [(64, 32, 64, 1, 'ls-1'), (64, 32, 128, 2, 'ls-1'), (128, 16, 128, 1, 'ls-1'),
-                                             (256, 8, 512, 2, 'ls-1'), (512, 4, 512, 1, 'ls-1'), (128, 16, 64, 1, 'ls-2'),
-                                             (64, 6, 48, 1, 'gf-3'), (192, 10, 50, 1, 'ls-1')])
-def test_fused_small_image_layer_equals_the_two_kernels(c, h, o, stride, ws):
-    """lsq_ls1_conv2d (quantizer + convolution in one launch, plane in LDS) against lsq_act_quant + lsq_xnor_conv2d on the
-    CIFAR layer shapes of cifar100_ls1_kd.yaml and a few odd ones: the activation scale and every output BIT FOR BIT, with the
-    folded batch norm, both shortcut positions, ReLU / PReLU, one to three weight planes; and against the oracle (1e-4)."""
-    from oracle import ref_port as P
-    from quant.binary.binary_conv import QuantConv2d
-    clamp = {'kind': 'symmetric', 'alpha': 2}
-    conv = QuantConv2d('ls-1', ws, c, o, 3, clamp, stride=stride, padding=1, bias=True)
-    with torch.no_grad():
-        conv.weight.copy_(detgen.normal(f'r4.small.w.{c}.{o}', conv.weight.shape, scale=0.2))
-        conv.bias.copy_(detgen.normal(f'r4.small.b.{o}', conv.bias.shape, scale=0.1))
-        for buf, v in zip(conv.w_approximate.cached_scales(), P.weight_scales(conv.weight, ws)):
-            buf.copy_(v)
-    bn = torch.nn.BatchNorm2d(c)
-    detgen.fill_module(bn, seed=3)
-    conv.eval().to(DEV)
-    bn.eval().to(DEV)
-    n = 5
-    x = detgen.normal(f'r4.small.x.{c}.{h}', (n, c, h, h), scale=1.3).to(DEV)
-    x.view(-1)[::13] = 0.0
-    x.view(-1)[5::17] = -0.0
-    ho = (h - 1) // stride + 1
-    res = detgen.normal(f'r4.small.r.{o}.{ho}', (n, o, ho, ho)).to(DEV)
-    slope = detgen.uniform('r4.small.slope', (o,), 0.1, 0.4).to(DEV)
-    cases = [dict(), dict(pre_bn=bn, relu=True, res_post=res), dict(pre_bn=bn, relu=True, res_pre=res),
-             dict(prelu=slope, res_pre=res, res_post=res)]
-    with torch.no_grad():
-        for kw in cases:
-            conv.fuse_small = True
-            y1 = conv.fused_forward(x, **kw).clone()
-            s1 = conv.last_act_scales.clone()
-            conv.fuse_small = False
-            y2 = conv.fused_forward(x, **kw).clone()
-            s2 = conv.last_act_scales.clone()
-            assert s1.shape == s2.shape and torch.equal(s1, s2), (c, h, kw.keys())
-            assert torch.equal(y1, y2), (c, h, list(kw), float((y1 - y2).abs().max()))
-        conv.fuse_small = True
-        y = conv(x).cpu()
-    y_or = P.quant_conv2d(x.cpu(), conv.weight.detach().cpu(), conv.bias.detach().cpu(), 'ls-1', ws,
-                          [b.cpu() for b in conv.w_approximate.cached_scales()], clamp, stride, 1)
-    assert float((y - y_or).abs().max()) <= 1e-4 * float(y_or.abs().max())
-
-
-def test_fused_small_image_path_is_taken_and_refuses_what_it_does_not_cover():
+# ------------------------------------------------------------------------------------------------ chained 1-bit layers
+@pytest.mark.parametrize('which,batch', [('cifar', 100), ('cifar', 7), ('imagenet_ls1', 6)])
+def test_chained_one_bit_layers_equal_the_unchained_network(which, batch):
+    """quant.binary.chain: with ls-1 activations every QuantConv2d after the first gets its bit plane and its exact row sum
+    from the epilogue of the convolution in front of it (lsq_xnor_conv2d_chain) -- 15 of the 16 quantizer launches of a
+    CIFAR ResNet-18 disappear (layers of more than chain.MAX_ELEMENTS elements keep theirs) -- and the logits are those of the unchained network BIT FOR BIT, eagerly and under graph replay."""
+    import bench
+    from quant.binary import chain
+    from quant.common.graph_replay import GraphedForward
     hip = _hip()
-    import ctypes
-    lib = hip.lib()
-    x = torch.randn(2, 64, 8, 8, device=DEV)
-    y = torch.empty(2, 64, 8, 8, device=DEV)
-    sc = torch.empty(1, 2, device=DEV)
-    wb = torch.zeros(9 * 64, dtype=torch.int64, device=DEV)
-    wsum = torch.zeros(64 * 9, dtype=torch.int32, device=DEV)
-    wsc = torch.ones(1, 64, device=DEV)
+    if which == 'cifar':
+        model = bench.build_model(bench.cifar_arch(), DEV)
+        x = torch.randn(batch, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to(DEV)
+    else:
+        model = bench.build_model(bench.imagenet_arch('ls-1', 2), DEV)       # PReLU blocks, 7x7 stem + max-pool
+        x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(DEV)
+    out, calls = {}, {}
+    for on in (False, True):
+        chain.ENABLED = on
+        try:
+            with torch.no_grad():
+                model(x)
+                hip.enable_timing(True)
+                out[on] = model(x).clone()
+                torch.cuda.synchronize()
+                calls[on] = {k: v[0] for k, v in hip.drain_timing().items()}
+                hip.enable_timing(False)
+        finally:
+            chain.ENABLED = True
+            hip.enable_timing(False)
+    assert calls[False]['lsq_act_quant'] == 16 and calls[False]['lsq_xnor_conv2d'] == 16, calls
+    # (layers of more than chain.MAX_ELEMENTS elements would keep their own quantizer launch: none at these batch sizes)
+    assert calls[True]['lsq_act_quant'] == 1 and calls[True]['lsq_xnor_conv2d'] == 16, calls
+    assert torch.equal(out[True], out[False]), float((out[True] - out[False]).abs().max())
+    fwd = GraphedForward(model, x)
+    assert torch.equal(fwd.replay(), out[False])
+    # and against the oracle's logits for this very model (free-running: no search in ls-1, so 1e-4 of max |logit| + the
+    # stem's fp differences amplified -- the bound of the unchained network)
+    from oracle import ref_models
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    arch = bench.cifar_arch() if which == 'cifar' else bench.imagenet_arch('ls-1', 2)
+    ref = ref_models.resnet_forward(sd, arch, x.cpu()[:4])
+    got = out[True].cpu()[:4]
+    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
-    def call(geom, alpha=2.0, xx=x):
-        return lib.lsq_ls1_conv2d(xx.data_ptr(), ctypes.byref(geom), alpha, None, None, wb.data_ptr(), wsum.data_ptr(), 1,
-                                  wsc.data_ptr(), None, 0, None, None, None, y.data_ptr(), sc.data_ptr(), None)
-    g = hip.make_geom(2, 64, 8, 8, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
-    assert call(g) == 0
-    assert call(g, alpha=-1.0) == -6                                         # no clamp: no exact row sum
-    assert call(hip.make_geom(2, 64, 8, 8, 64, 3, 3, (1, 1), (1, 1), (2, 2), 1)) == -6      # dilation
-    assert call(hip.make_geom(2, 64, 8, 8, 64, 5, 5, (1, 1), (2, 2), (1, 1), 1)) == -6      # 5 x 5
-    assert call(hip.make_geom(2, 64, 8, 8, 64, 3, 3, (1, 1), (1, 1), (1, 1), 2)) == -6      # groups
-    assert call(hip.make_geom(2, 48, 8, 8, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)) == -6      # 48 channels
-    assert call(hip.make_geom(2, 64, 40, 40, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)) == -6    # image too large for the LDS plane
-    assert lib.lsq_ls1_conv2d(None, ctypes.byref(g), 2.0, None, None, wb.data_ptr(), wsum.data_ptr(), 1, wsc.data_ptr(), None, 0,
-                              None, None, None, y.data_ptr(), sc.data_ptr(), None) == -1
-    torch.cuda.synchronize()
+
+def test_lone_row_split_sweep_replayed_in_a_graph():
+    """A HIP graph re-issues a captured launch with the SAME arguments -- the arrival slots' epoch among them.  One ls-1
+    sweep of few rows (shared by several workgroups each), captured alone and replayed on new data: every replay writes
+    every scale (the last arrival releases the slot; with the epoch alone the second replay found a full count)."""
+    hip = _hip()
+    n, c, h, w = 4, 64, 32, 32
+    geom = hip.make_geom(n, c, h, w, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+    x = torch.randn(n, c, h, w, device=DEV)
+    planes = torch.zeros((hip.act_plane_words(geom),), dtype=torch.int64, device=DEV)
+    scales = torch.zeros((1, n), device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip.act_quant(x, geom, hip.SCHEME_LS1, 1, 3, 2.0, planes, scales)          # (allocates the stream's sweep workspace)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        hip.act_quant(x, geom, hip.SCHEME_LS1, 1, 3, 2.0, planes, scales)
+    for seed in range(4):
+        x.copy_(torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(seed)).to(DEV) * (seed + 1))
+        scales.fill_(-1.0)
+        graph.replay()
+        want = x.clamp(-2.0, 2.0).abs().double().mean(dim=(1, 2, 3)).float()
+        assert torch.allclose(scales[0], want, rtol=1e-6, atol=0), (seed, scales, want)
