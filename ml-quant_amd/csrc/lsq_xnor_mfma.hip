@@ -188,7 +188,15 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     wring[i][0] = s_w[2 * i][lane];
     wring[i][1] = s_w[2 * i + 1][lane];
   }
+#ifdef LSQ_XNOR_CLOCKS
+  long long clk[15];
+  int nclk = 0;
+#define XCLK() do { __builtin_amdgcn_sched_barrier(0); if (nclk < 15) clk[nclk++] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define XCLK() do {} while (0)
+#endif
   for (;;) {
+    XCLK();
     const int nxt = tile + tstride;
     const bool more = nxt < ntiles;
     Pix nx = cur;
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       }
     }
 
+    XCLK();
     // ---- epilogue of this tile: the popcount kernel's arithmetic on the same integers -> the same floats --------
     float nqv[CHAIN ? 16 : 1];                   // (chained layers: the tile's outputs, kept for the next layer's quantizer)
     if constexpr (CHAIN) {
@@ -314,6 +323,10 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
         for (int p = 1; p < KX; ++p) v = fmaf(xs[p], (float)acc[p][i], v);
         outv[i] = fmaf(v, reinterpret_cast<const float*>(&scv[i >> 2])[i & 3], basev[i]);
       }
+#ifdef LSQ_XNOR_CLOCKS
+      asm volatile("" :: "v"(outv[0]), "v"(outv[15]));
+      XCLK();
+#endif
       if (want_pre) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) outv[i] += rv[i];
@@ -323,8 +336,16 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
         for (int i = 0; i < 16; ++i) outv[i] = fmaxf(outv[i], 0.f);
       }
       if (prelu) {
+        // (slopes as four 16-byte reads and the product taken unconditionally: written as `v > 0 ? v : slope * v` with the
+        //  slope read inside, the compiler emitted sixteen branches with an LDS round trip each)
+        float4 slv[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) outv[i] = outv[i] > 0.f ? outv[i] : s_slope[ob + (i & 3) + 8 * (i >> 2)] * outv[i];
+        for (int g = 0; g < 4; ++g) slv[g] = *reinterpret_cast<const float4*>(&s_slope[ob + 8 * g]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float neg = reinterpret_cast<const float*>(&slv[i >> 2])[i & 3] * outv[i];
+          outv[i] = outv[i] > 0.f ? outv[i] : neg;
+        }
       }
       if (want_post && !want_pre) {
 #pragma unroll
@@ -334,6 +355,10 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) outv[i] += (a.res_post + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
       }
+#ifdef LSQ_XNOR_CLOCKS
+      asm volatile("" :: "v"(outv[0]), "v"(outv[15]));
+      XCLK();
+#endif
 #pragma unroll
       for (int i = 0; i < 16; ++i) (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff] = outv[i];
       if constexpr (CHAIN) {
@@ -394,10 +419,17 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       }
     }
 
+    XCLK();
     if (!more) break;
     tile = nxt;
     cur = nx;
   }
+#ifdef LSQ_XNOR_CLOCKS
+  // dev build: the time stamps of (tile start, main loop end, epilogue end) x 4 tiles of wave 0 of workgroups 0..3 overwrite
+  // the start of y (the caller reads them as int64)
+  if (lane == 0 && wid == 0 && blockIdx.y == 0 && blockIdx.x < 4)
+    for (int i = 0; i < 15; ++i) reinterpret_cast<long long*>(a.y)[blockIdx.x * 15 + i] = i < nclk ? clk[i] : 0;
+#endif
 }
 
 template <int KX, int GG>

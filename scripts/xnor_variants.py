@@ -10,7 +10,7 @@ from quant import _hip  # noqa: E402
 from kbench import SHAPES, timeit  # noqa: E402
 
 n, dev, k = 256, 'cuda:0', 2
-tot = [0.0, 0.0, 0.0]
+tot = [0.0, 0.0, 0.0, 0.0]
 for c, h, o, stride, count in SHAPES:
     x = torch.randn(n, c, h, h, device=dev)
     w = torch.randn(o, c, 3, 3, device=dev)
@@ -27,7 +27,9 @@ for c, h, o, stride, count in SHAPES:
     t0 = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), 10)
     t1 = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y, relu=True), 10)
     t2 = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y, relu=True, res_pre=res), 10)
-    for i, t in enumerate((t0, t1, t2)):
+    slope = torch.full((o,), 0.25, device=dev)
+    t3 = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y, res_pre=res, prelu=slope), 10)
+    for i, t in enumerate((t0, t1, t2, t3)):
         tot[i] += t * count
-    print(f'C={c:4d} H={h:3d} O={o:4d} s={stride} | plain {t0:6.1f}  +relu {t1:6.1f}  +relu+res {t2:6.1f}   (x{count})')
-print('per forward: plain %.2f ms, +relu %.2f ms, +relu+res %.2f ms' % tuple(t / 1e3 for t in tot))
+    print(f'C={c:4d} H={h:3d} O={o:4d} s={stride} | plain {t0:6.1f}  +relu {t1:6.1f}  +relu+res {t2:6.1f}  +prelu+res {t3:6.1f}   (x{count})')
+print('per forward: plain %.2f ms, +relu %.2f ms, +relu+res %.2f ms, +prelu+res %.2f ms' % tuple(t / 1e3 for t in tot))
