@@ -193,8 +193,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
     }
   };
   if constexpr (kPrefetch) request(0, 0, pre);
+#ifdef LSQ_STEM_CLOCKS
+  long long clk[24];
+  int nclk = 0;
+#define SCLK() do { __builtin_amdgcn_sched_barrier(0); if (nclk < 24) clk[nclk++] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SCLK() do {} while (0)
+#endif
+  SCLK();
   for (int ck = 0; ck < chunks; ++ck) {
     __syncthreads();                      // the previous chunk's patch and hbuf are done with
+    SCLK();
     if constexpr (kPrefetch) {
       convert(0, pre);
     } else {
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       }
     }
     __syncthreads();
+    SCLK();
     if constexpr (kPrefetch) {
       if (ck + 1 < chunks) request(ck + 1, 0, pre);
     }
@@ -234,14 +244,15 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
         if (s + 1 < kSteps) load_b(s + 1, (s + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         const Frag* b = bf[s & 1];
+        // (the leading product BETWEEN the two cross terms: two MFMAs on the same accumulator back to back wait for each other)
         if constexpr (HALF) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][s].h, b[0].h, acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][s].h, b[0].h, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][s].h, b[1].h, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][s].h, b[0].h, acc1, 0, 0, 0);
         } else {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[0].v, acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[0].v, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[1].v, acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[0].v, acc1, 0, 0, 0);
           if constexpr (SPLIT == 3) {
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[2].v, acc1, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][s].v, b[0].v, acc1, 0, 0, 0);
@@ -282,7 +293,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
           *reinterpret_cast<float4*>(&lds.carry[q][mt][g][4 * k]) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
       }
     }
+    SCLK();
     __syncthreads();
+    SCLK();
     // ---- vertical 3-max (stride 2), bias, ReLU, store: 64 channels x 4 pooled rows x 16 pooled columns
     if ((a.Wp & 3) == 0) {
       // four columns per lane: 16-byte LDS reads and global stores (a group of four is inside the row or outside it)
@@ -320,6 +333,13 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       }
     }
   }
+  SCLK();
+#ifdef LSQ_STEM_CLOCKS
+  // dev build: wave 0 of the workgroups 1024..1027 (a middle round) overwrites the start of y with its stamps: per chunk
+  // (barrier, convert + barrier, rows: MFMAs + horizontal max, barrier, vertical max + stores)
+  if (tid == 0 && blockIdx.x >= 1024 && blockIdx.x < 1028)
+    for (int i = 0; i < 24; ++i) reinterpret_cast<long long*>(a.y)[(blockIdx.x - 1024) * 24 + i] = i < nclk ? clk[i] : 0;
+#endif
   if constexpr (HALF) {
     if (a.overflow && __builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.overflow, 1);
   }

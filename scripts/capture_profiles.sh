@@ -35,5 +35,7 @@ for u in valu_rates launch_overhead; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o /tmp/$u 2> $o/$u.build.log && /tmp/$u > $o/${tag}_ubench_$u.txt 2>&1
 done
 python scripts/kbench.py > $o/${tag}_kbench.txt 2>&1
+python scripts/ls1_chain.py > $o/${tag}_ls1_chain.txt 2>&1
+python scripts/xnor_variants.py > $o/${tag}_xnor_variants.txt 2>&1
 python scripts/kbench.py --fold > $o/${tag}_kbench_bnfold.txt 2>&1
 head -3 $o/${tag}_rocprofv3_per_step_summary.csv; cut -c1-300 $o/${tag}_bench_n1_ls2.json; cut -c1-160 $o/${tag}_bench_n1_fpact.json
