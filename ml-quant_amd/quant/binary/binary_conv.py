@@ -237,6 +237,8 @@ class QuantConv2d(nn.Conv2d):
             return None
         if conv.in_channels != self.out_channels or conv.groups != 1 or isinstance(conv.padding, str) or conv.padding_mode != 'zeros':
             return None
+        if conv.weight.device != device or (bn is not None and bn.running_mean.device != device):
+            return None                 # (a replica whose ``chain_next`` still names the original module, e.g. nn.DataParallel)
         if conv._alpha() <= 0 or conv.x_approximate.eval_scales(n) is not None:
             return None
         if bn is not None and (bn.training or not bn.track_running_stats):
@@ -322,8 +324,7 @@ class QuantConv2d(nn.Conv2d):
                                           relu, res_pre, res_post, prelu, None if target is None else target[0]):
                     self.last_act_scales = scales_in          # (None when the scale came from the producer's row sums)
                     if target is not None:
-                        y._lsq_pre = target[1]
-                        y._lsq_keep = target[2]
+                        chain.attach(y, target[1], target[2])
                     return y
                 if handed is None and scales_in is not None:   # outside the matrix-core kernel: the plain call, same planes
                     _hip.xnor_conv2d(planes_in, k, scales_in, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)

@@ -32,10 +32,11 @@ _arenas = {}
 class PreQuant:
     """The next layer's 1-bit input as its producer left it: plane words + row sums in units of 2^e."""
 
-    __slots__ = ('consumer', 'pre_bn', 'planes', 'units', 'shape', 'stream')
+    __slots__ = ('consumer', 'pre_bn', 'planes', 'units', 'shape', 'stream', 'version')
 
     def __init__(self, consumer, pre_bn, planes, units, shape, stream):
         self.consumer, self.pre_bn, self.planes, self.units, self.shape, self.stream = consumer, pre_bn, planes, units, shape, stream
+        self.version = None             # ``_version`` of the tensor the record rides on: an in-place edit of it voids the record
 
 
 @contextlib.contextmanager
@@ -74,5 +75,18 @@ def accumulator(n: int, device) -> torch.Tensor:
     return out
 
 
+def attach(y: torch.Tensor, record: PreQuant, keep) -> None:
+    """Hand ``record`` to whoever consumes ``y`` next (an attribute of the tensor OBJECT: a view, a copy or a new tensor
+    does not carry it, and the consumer then quantizes for itself)."""
+    record.version = y._version
+    y._lsq_pre = record
+    y._lsq_keep = keep
+
+
 def pending(x: torch.Tensor) -> Optional[PreQuant]:
-    return getattr(x, '_lsq_pre', None) if ENABLED else None
+    """The record a producer left on ``x`` -- unless ``x`` was written to since (a hook, ``x.add_(...)``): the planes and row
+    sums describe the values the producer stored, so the consumer must quantize what is there now."""
+    rec = getattr(x, '_lsq_pre', None) if ENABLED else None
+    if rec is not None and rec.version != x._version:
+        return None
+    return rec

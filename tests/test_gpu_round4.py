@@ -336,3 +336,33 @@ def test_lone_row_split_sweep_replayed_in_a_graph():
         graph.replay()
         want = x.clamp(-2.0, 2.0).abs().double().mean(dim=(1, 2, 3)).float()
         assert torch.allclose(scales[0], want, rtol=1e-6, atol=0), (seed, scales, want)
+
+
+def test_chained_record_is_void_after_an_in_place_edit():
+    """The plane and row sums a producer leaves for its consumer describe the values it STORED: a forward hook that edits the
+    tensor in place between two blocks (its ``_version`` moves) makes the consumer quantize what is there now -- the network
+    with the hook gives the same logits chained and unchained, bit for bit, and one more quantizer launch runs."""
+    import bench
+    from quant.binary import chain
+    hip = _hip()
+    model = bench.build_model(bench.cifar_arch(), DEV)
+    x = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+    blocks = [m for m in model.modules() if type(m).__name__ == 'XnorBasicBlock']
+    handle = blocks[2].register_forward_hook(lambda mod, inp, out: out.add_(0.25))
+    out, quant_calls = {}, {}
+    try:
+        for on in (False, True):
+            chain.ENABLED = on
+            with torch.no_grad():
+                model(x)
+                hip.enable_timing(True)
+                out[on] = model(x).clone()
+                torch.cuda.synchronize()
+                quant_calls[on] = hip.drain_timing()['lsq_act_quant'][0]
+                hip.enable_timing(False)
+    finally:
+        chain.ENABLED = True
+        hip.enable_timing(False)
+        handle.remove()
+    assert torch.equal(out[True], out[False])
+    assert quant_calls[False] == 16 and quant_calls[True] == 2, quant_calls      # the first layer + the consumer behind the hook
