@@ -33,7 +33,8 @@ class ConvGeom(ctypes.Structure):
         'pad_h', 'pad_w', 'dil_h', 'dil_w', 'groups')]
 
     def key(self):
-        return tuple(getattr(self, n) for n, _ in self._fields_)
+        k = self.__dict__.get('_key')             # (make_geom leaves the tuple it was built from: 14 ctypes field reads otherwise)
+        return k if k is not None else tuple(getattr(self, n) for n, _ in self._fields_)
 
 
 class NextLs1(ctypes.Structure):
@@ -154,6 +155,7 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 _SAME_DEVICE = contextlib.nullcontext()
+_UNTIMED = contextlib.nullcontext()
 
 
 def _on(t: torch.Tensor):
@@ -169,8 +171,10 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def make_geom(n, c, h, w, o, kh, kw, stride, padding, dilation, groups) -> ConvGeom:
-    return ConvGeom(n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1],
-                    dilation[0], dilation[1], groups)
+    key = (n, c, h, w, o, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], groups)
+    g = ConvGeom(*key)
+    g._key = key                                   # (valid as long as nobody writes the fields afterwards: nothing here does)
+    return g
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -301,7 +305,8 @@ def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, a
     if forced is None:
         ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) else sweep_workspace(geom.N, x.device)
     m = geom.C * geom.H * geom.W
-    with _on(x), _Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8), 0, f'C{geom.C}_H{geom.H}'):     # x read once + k bit planes written
+    # (accounting -- x read once + k bit planes written -- only when a benchmark asked for it: the record costs microseconds)
+    with _on(x), (_Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8), 0, f'C{geom.C}_H{geom.H}') if _timing is not None else _UNTIMED):
         check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha),
                                   None if pre is None else pre[0].data_ptr(), None if pre is None else pre[1].data_ptr(),
                                   ptr(forced), planes.data_ptr(), scales.data_ptr(), ptr(ws),
@@ -371,8 +376,8 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
     nres = (res_pre is not None) + (res_post is not None)
     # algorithmic bytes: planes read + fp32 output written + every residual operand of the fused epilogue read
-    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
-                         geom.N * kx * m // 8 + 4 * y.numel()):
+    with _on(y), (_Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
+                         geom.N * kx * m // 8 + 4 * y.numel()) if _timing is not None else _UNTIMED):
         check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
                                     wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
                                     ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
@@ -395,8 +400,8 @@ def xnor_conv2d_chain(planes: torch.Tensor, xscales: Optional[torch.Tensor], x_u
     nres = (res_pre is not None) + (res_post is not None)
     macs = y.numel() * geom.C * geom.KH * geom.KW * wscales.shape[0]
     extra = 0 if nxt is None else y.numel() // 8
-    with _on(y), _Timed('lsq_xnor_conv2d', geom.N * m // 8 + 4 * y.numel() * (1 + nres) + extra, macs,
-                         f'C{geom.C}_H{geom.H}_s{geom.stride_h}', geom.N * m // 8 + 4 * y.numel()):
+    with _on(y), (_Timed('lsq_xnor_conv2d', geom.N * m // 8 + 4 * y.numel() * (1 + nres) + extra, macs,
+                         f'C{geom.C}_H{geom.H}_s{geom.stride_h}', geom.N * m // 8 + 4 * y.numel()) if _timing is not None else _UNTIMED):
         code = lib().lsq_xnor_conv2d_chain(planes.data_ptr(), ptr(xscales), ptr(x_units), float(x_alpha), wbits.data_ptr(),
                                            wsum.data_ptr(), wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom),
                                            act, ptr(slope), ptr(res_pre), ptr(res_post),

@@ -131,6 +131,17 @@ class QuantConv2d(nn.Conv2d):
         """The limits of the kernels (include/lsq_hip.h); anything outside them takes the torch formulation,
         exactly as training and CPU tensors do: fp32 only, at most 8 bit planes, kernels up to 8x8 on the
         XNOR path, at most 2^22 sub-sampled keys per row for the LS-2 / LS-T solve."""
+        # (memoised per input dtype and row shape: the rest is fixed at construction; _apply -- .to(), .half() -- clears the cache)
+        key = ('sup', x.dtype, x.shape[1], x.shape[2], x.shape[3])
+        hit = self._hip_cache.get(key)
+        if hit is None:
+            if sum(1 for kk in self._hip_cache if isinstance(kk, tuple) and kk[0] == 'sup') >= 16:      # (many image sizes)
+                for kk in [kk for kk in self._hip_cache if isinstance(kk, tuple) and kk[0] == 'sup']:
+                    del self._hip_cache[kk]
+            hit = self._hip_cache[key] = self._hip_supports_uncached(x)
+        return hit
+
+    def _hip_supports_uncached(self, x: torch.Tensor) -> bool:
         from quant import _hip
         if x.dtype != torch.float32 or self.weight.dtype != torch.float32:
             return False
@@ -172,8 +183,8 @@ class QuantConv2d(nn.Conv2d):
     def _packed_weights(self, geom, _hip):
         wq = self.w_approximate
         bufs = wq.cached_scales()
-        stamp = (self.weight._version, self.weight.data_ptr(), tuple(b._version for b in bufs),
-                 tuple(b.data_ptr() for b in bufs), geom.key()[4:])
+        w = self._parameters['weight']
+        stamp = (w._version, w.data_ptr(), geom.key()[4:]) + tuple((b._version, b.data_ptr()) for b in bufs)
         hit = self._hip_cache.get('w')
         if hit is None or hit[0] != stamp:
             scales = wq.plane_scales().to(torch.float32).contiguous()
