@@ -39,8 +39,9 @@ constexpr unsigned kM0 = 0x01010101u;
 // The weight fragments are re-read from LDS for every tile (conflict-free ds_read_b128 at 256 B/clk: a quarter of the
 // LDS bandwidth at full MFMA rate); keeping the 72 VGPRs of the 64-channel case in registers instead measured slower
 // once the epilogue inputs were requested early (fewer waves per SIMD).
-// NWAVES: waves per workgroup, all on the same 32 out-channels (8 when the fragments of 512 channels fill the LDS of
-// a CU: one workgroup per CU, still two waves per SIMD).
+// NWAVES: waves per workgroup, all on the same 32 out-channels: 8 -- one workgroup per CU, two waves per SIMD -- for 256 and
+// 512 channels (the fragments of 512 channels fill the LDS of a CU; at 256 channels one workgroup of 8 waves expands
+// the weights and builds the tables ONCE where two workgroups of 4 did it twice: 59-60 -> 55-56 us per 14 x 14 layer, round 4).
 template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN>
 __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
   constexpr int NT = 64 * NWAVES;
@@ -434,10 +435,11 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 
 template <int KX, int GG>
 int launch(const ConvArgs& a, hipStream_t st) {
-  constexpr int NWAVES = GG >= 8 ? 8 : 4;
-  // workgroups per CU: the weight fragments of 256 / 512 channels fill half / all of the LDS; below that three
-  // workgroups (168 VGPRs each) hide more of the epilogue's memory latency than two
-  constexpr int WPC = GG >= 8 ? 1 : GG >= 4 ? 2 : 3;
+  constexpr int NWAVES = GG >= 4 ? 8 : 4;
+  // workgroups per CU: one of 8 waves for 256 / 512 channels (see NWAVES above); below that three workgroups of 4 waves
+  // (168 VGPRs each) hide more of the epilogue's memory latency than two (re-measured in round 4: 128 channels on two
+  // workgroups or on one of 8 waves: no better)
+  constexpr int WPC = GG >= 4 ? 1 : 3;
   const long long total = (long long)a.N * a.Ho * a.Wo;
   const long long ntiles = (total + 31) >> 5;
   const int n_ot = a.O / 32;
