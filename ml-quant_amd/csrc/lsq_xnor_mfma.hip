@@ -134,36 +134,81 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   // ---- once per workgroup: weight fragments and epilogue tables of its 32 out-channels ----------------------------
   // one thread = one (fragment pair, lane) entry: the weight word's dword of the lane's half, eight registers of four
   // bytes +-(64 >> q): bytes (d >> q) & 0x01010101 -> 0x00 / 0xFF masks -> select between the two byte patterns
-  for (int e = tid; e < TAPS * GG * 64; e += NT) {
-    const int L = e & 63, tj = e >> 6;
+  // EVERY global load of the set-up goes out first -- the weight words of all of the thread's entries, its tap sums, the
+  // channel's scale / bias / slope -- and is waited for once: written as "load, expand, store" per entry the loop paid one
+  // L2 round trip per entry, up to nine in a row (round 4: the set-up was a tenth of the 256-channel launches).
+  constexpr int kWEntries = TAPS * GG * 64, kWIter = (kWEntries + NT - 1) / NT;
+  constexpr int kSIter = (TAPS * 32 + NT - 1) / NT;
+  auto entry = [&](int e, int& L, int& tj, int& pos) {
+    L = e & 63;
+    tj = e >> 6;
     const int fj = tj / TAPS, ft = tj - fj * TAPS;                                               // fragment order: word-major
     // step ft = (kernel row, dword dd of the lane's 12 bytes): half 0 holds (kw 0 low, kw 0 high, kw 1 low), half 1
     // (kw 1 high, kw 2 low, kw 2 high)
     const int fkh = ft / 3, dd = ft - 3 * fkh, lh = L >> 5;
-    const int pos = 3 * lh + dd;                                                                  // 0..5: dword of the 24 bytes
+    pos = 3 * lh + dd;                                                                            // 0..5: dword of the 24 bytes
     const int tap = 3 * fkh + (pos >> 1);
-    const unsigned long long w = a.wbits[(long long)(tap * GG + fj) * a.opad_total + o0 + (L & 31)];   // [tap][word][O]
-    const unsigned d = (pos & 1) ? (unsigned)(w >> 32) : (unsigned)w;
-    v4i out[2];
+    return (long long)(tap * GG + fj) * a.opad_total + o0 + (L & 31);                             // [tap][word][O]
+  };
+  unsigned long long wword[kWIter];
+  int wsv[kSIter];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const unsigned mag = q < 7 ? (64u >> q) : 64u;
-      const unsigned pos = mag * kM0, neg = ((256u - mag) & 0xFFu) * kM0;
-      const unsigned ones = (d >> q) & kM0;
-      const unsigned mask = (ones << 8) - ones;                                                  // 0xFF where the bit is set
-      out[q >> 2][q & 3] = (int)(neg ^ ((pos ^ neg) & mask));
-    }
-    s_w[2 * tj][L] = out[0];
-    s_w[2 * tj + 1][L] = out[1];
+  for (int k = 0; k < kWIter; ++k) {
+    int L, tj, pos;
+    const int e = tid + k * NT;
+    const long long at = entry(e < kWEntries ? e : 0, L, tj, pos);
+    wword[k] = a.wbits[at];
   }
-  for (int i = tid; i < TAPS * 32; i += NT) s_ws[i >> 5][i & 31] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
+#pragma unroll
+  for (int k = 0; k < kSIter; ++k) {
+    const int i = min(tid + k * NT, TAPS * 32 - 1);
+    wsv[k] = a.wsum[(long long)(o0 + (i & 31)) * TAPS + (i >> 5)];
+  }
+  float c_sc = 0.f, c_bi = 0.f, c_sl = 0.f, c_ns = 1.f, c_nt = 0.f;
   if (tid < 32) {
-    s_scale[tid] = a.wscale[o0 + tid];
-    s_bias[tid] = a.bias ? a.bias[o0 + tid] : 0.f;
-    s_slope[tid] = a.relu >= LSQ_ACT_PRELU ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o0 + tid] : 0.f;   // (0: ReLU)
+    c_sc = a.wscale[o0 + tid];
+    c_bi = a.bias ? a.bias[o0 + tid] : 0.f;
+    c_sl = a.relu >= LSQ_ACT_PRELU ? a.slope[a.relu == LSQ_ACT_PRELU ? 0 : o0 + tid] : 0.f;     // (0: ReLU)
     if constexpr (CHAIN) {
-      s_nqs[tid] = (a.nq_planes32 && a.nq_scale) ? a.nq_scale[o0 + tid] : 1.f;
-      s_nqt[tid] = (a.nq_planes32 && a.nq_scale) ? a.nq_shift[o0 + tid] : 0.f;
+      c_ns = (a.nq_planes32 && a.nq_scale) ? a.nq_scale[o0 + tid] : 1.f;
+      c_nt = (a.nq_planes32 && a.nq_scale) ? a.nq_shift[o0 + tid] : 0.f;
+    }
+  }
+  // one thread = one (fragment pair, lane) entry: the weight word's dword of the lane's half, eight registers of four
+  // bytes +-(64 >> q): bytes (d >> q) & 0x01010101 -> 0x00 / 0xFF masks -> select between the two byte patterns
+#pragma unroll
+  for (int k = 0; k < kWIter; ++k) {
+    const int e = tid + k * NT;
+    if (e < kWEntries) {
+      int L, tj, pos;
+      entry(e, L, tj, pos);
+      const unsigned long long w = wword[k];
+      const unsigned d = (pos & 1) ? (unsigned)(w >> 32) : (unsigned)w;
+      v4i out[2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned mag = q < 7 ? (64u >> q) : 64u;
+        const unsigned pos = mag * kM0, neg = ((256u - mag) & 0xFFu) * kM0;
+        const unsigned ones = (d >> q) & kM0;
+        const unsigned mask = (ones << 8) - ones;                                                // 0xFF where the bit is set
+        out[q >> 2][q & 3] = (int)(neg ^ ((pos ^ neg) & mask));
+      }
+      s_w[2 * tj][L] = out[0];
+      s_w[2 * tj + 1][L] = out[1];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kSIter; ++k) {
+    const int i = tid + k * NT;
+    if (i < TAPS * 32) s_ws[i >> 5][i & 31] = wsv[k];
+  }
+  if (tid < 32) {
+    s_scale[tid] = c_sc;
+    s_bias[tid] = c_bi;
+    s_slope[tid] = c_sl;
+    if constexpr (CHAIN) {
+      s_nqs[tid] = c_ns;
+      s_nqt[tid] = c_nt;
     }
   }
   __syncthreads();
