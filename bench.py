@@ -347,6 +347,8 @@ def main():
                     help='cpu: plumbing check of the launcher and the collective (gloo, torch formulation of the model); never a benchmark')
     ap.add_argument('--image-size', type=int, default=224, help='(plumbing checks only; the metric is quoted at 224)')
     ap.add_argument('--no-pin', action='store_true', help='do not pin the rank to the cores of its GPU\'s NUMA node')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='HIP streams consecutive steps alternate between in the second timed region (1: only the single-stream region)')
     args = ap.parse_args()
 
     from quant.common import rank_launcher
@@ -468,6 +470,55 @@ def main():
     timed_table = _hip.drain_timing() if roofline else {}
     _hip.enable_timing(False)
 
+    # ---- second timed region: the same steps, consecutive ones on alternating HIP streams (quant/common/stream_pipeline.py:
+    # what quant.common.training.evaluate does with consecutive batches).  Same bracket: EXACTLY args.steps steps between
+    # barrier + synchronize, repeated until args.min_seconds have been timed, max over ranks per bracket.  The all-gather
+    # of a step's logits stays on the one main stream, ordered after that step's forward.
+    piped = None
+    if cuda and args.streams > 1:
+        from quant.common.stream_pipeline import StreamPipeline
+        pipe = StreamPipeline(model, device, args.streams)
+
+        def run_pipelined(n):
+            window = []
+
+            def consume():
+                y = window.pop(0).result()
+                if in_group:
+                    all_gather_logits(y, gathered, always_collective=True)
+
+            for _ in range(n):
+                window.append(pipe.submit(x))
+                if len(window) >= pipe.depth:
+                    consume()
+            while window:
+                consume()
+
+        with torch.no_grad():
+            run_pipelined(max(args.warmup, 2 * args.streams))
+            p_elapsed, p_reps, p_rep_ms = 0.0, 0, []
+            while True:
+                if world > 1:
+                    dist.barrier()
+                sync()
+                t0 = time.perf_counter()
+                run_pipelined(args.steps)
+                if world > 1:
+                    dist.barrier()
+                sync()
+                dt = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([dt], dtype=torch.float64, device=device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                p_elapsed += dt
+                p_reps += 1
+                p_rep_ms.append(1e3 * dt / args.steps)
+                if p_elapsed >= args.min_seconds or p_reps >= 10000:
+                    break
+        piped = {'streams': args.streams, 'steps_timed': p_reps * args.steps, 'repetitions': p_reps, 'timed_seconds': p_elapsed,
+                 'ms_per_step': 1e3 * p_elapsed / (p_reps * args.steps), 'ms_per_step_best_repetition': min(p_rep_ms)}
+
     allgather = None
     if in_group:
         # the exchange step alone: [batch, 1000] fp32 logits per rank, events on the launch stream
@@ -514,6 +565,18 @@ def main():
             'path_frac_note': 'images/s per GPU / 628 k images/s = 8 TB/s over the 12.74 MB per image the 16 QuantConv2d '
                               'layers read and write once (SURVEY 8(d)); popcount roofline 376 k images/s (ls-2)',
         }
+        if piped is not None:
+            # `value` keeps the definition of rounds 1-3: consecutive steps on ONE stream, every kernel alone on the chip -- what
+            # `roofline` and the rocprofv3 summaries under profiles/ describe.  The two-stream region is reported BESIDE it, not
+            # instead of it: a reader comparing this line with an earlier round's compares like with like.
+            pvalue = world * args.batch * piped['steps_timed'] / piped['timed_seconds']
+            piped.update(value=pvalue, unit='images/sec', vs_single_stream=pvalue / value,
+                         path_frac=pvalue / world / PATH_ROOFLINE_IMG_S[args.act],
+                         note=('the same steps with consecutive ones alternating between %d HIP streams (quant/common/stream_pipeline.py, '
+                               'what quant.common.training.evaluate does with consecutive batches): the dispatch ramp and the last tiles '
+                               'of one step\'s kernels run under the next step\'s kernels; logits bit-identical to the single-stream '
+                               'forward.  NOT the definition of `value` in this or any earlier round' % piped['streams']))
+            out['pipelined'] = piped
         if not cuda:
             out.update(device='cpu', dtype='f32 (torch formulation)',
                        note='PLUMBING CHECK of the launcher and the gloo collective on the host -- not a measurement of the HIP path')
@@ -523,7 +586,8 @@ def main():
                                               batch=args.batch)     # events over the timed region
             launches, nbytes = timed_table[dominant][0], timed_table[dominant][2]
             out['roofline']['measured'] = ('HIP events around every launch of this kernel in the first step of every group of '
-                                           '%d steps of the timed region' % per)
+                                           '%d steps of the timed region (one stream: the kernel alone on the chip, as in the '
+                                           'rocprofv3 summaries under profiles/)' % per)
             out['roofline']['traffic'] = None
             pmc = pmc_traffic_per_launch(dominant, args.act) if args.batch == 256 and args.image_size == 224 else None
             if pmc and 'stale' in pmc:

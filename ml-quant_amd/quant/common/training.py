@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from quant.common.metrics import Metric
 from quant.common.sharded_eval import evaluate_sharded, local_slice
+from quant.common.stream_pipeline import StreamPipeline, eval_streams
 
 logger = logging.getLogger(__name__)
 Hook = Callable[..., None]
@@ -35,6 +36,18 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
         metric.reset()
     sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     batch_idx = -1
+    # consecutive batches alternate between two HIP streams (stream_pipeline.py: the dispatch ramp and the last tiles of one
+    # forward's kernels run under the other forward's kernels); the metrics of batch i - 1 are taken on THIS stream while
+    # batch i runs.  One stream on the CPU and for sharded batches: same order of operations as the reference's loop.
+    pipe = StreamPipeline(model, device, eval_streams(device, sharded))
+    window = []
+
+    def consume():
+        pending, target = window.pop(0)
+        output = pending.result()
+        for metric in metrics.values():
+            metric.update(output, target)
+
     with torch.no_grad():
         for batch_idx, (data, target) in enumerate(test_loader):
             target = target.to(device)
@@ -42,10 +55,14 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
                 # the shard is cut on the host: only this rank's samples cross PCIe
                 part = local_slice(data.shape[0], dist.get_rank(), dist.get_world_size())
                 output = evaluate_sharded(model, data[part].to(device), total=data.shape[0])
-            else:
-                output = model(data.to(device))
-            for metric in metrics.values():
-                metric.update(output, target)
+                for metric in metrics.values():
+                    metric.update(output, target)
+                continue
+            window.append((pipe.submit(data.to(device)), target))
+            if len(window) >= pipe.depth:
+                consume()
+        while window:
+            consume()
     for hook in hooks:
         hook(epoch=epoch, global_step=1 + (epoch - 1) * len(test_loader.dataset) + batch_idx)
     if torch.device(device).type == 'cuda':

@@ -12,12 +12,12 @@ python bench.py --act fp --no-configs > $o/${tag}_bench_n1_fpact.json 2> $o/benc
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 \
   --steps 100 --cpu-sample 0 --no-configs > $o/${tag}_bench_torchrun_n1_ls2.json 2> $o/bench_torchrun.err
 rm -rf $o/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_final -- python bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-configs > $o/prof_final.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_final -- python bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-configs --streams 1 > $o/prof_final.log 2>&1
 f=$(ls -t $o/prof_final/*/*kernel_trace.csv | head -1)
 python scripts/trace_summary.py $f 10 > $o/${tag}_rocprofv3_per_step_summary.csv
 cp $(ls -t $o/prof_final/*/*kernel_stats.csv | head -1) $o/${tag}_rocprofv3_kernel_stats_incl_warmup.csv
 rm -rf $o/prof_fp
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --steps 30 --warmup 5 --cpu-sample 0 --no-configs > $o/prof_fp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --steps 30 --warmup 5 --cpu-sample 0 --no-configs --streams 1 > $o/prof_fp.log 2>&1
 python scripts/trace_summary.py $(ls -t $o/prof_fp/*/*kernel_trace.csv | head -1) 10 > $o/${tag}_rocprofv3_per_step_summary_fpact.csv
 scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic.json > $o/pmc.log 2>&1
 scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic_fpact.json --act fp > $o/pmc_fp.log 2>&1

@@ -366,3 +366,39 @@ def test_chained_record_is_void_after_an_in_place_edit():
         handle.remove()
     assert torch.equal(out[True], out[False])
     assert quant_calls[False] == 16 and quant_calls[True] == 2, quant_calls      # the first layer + the consumer behind the hook
+
+
+def test_consecutive_batches_on_two_streams_equal_the_single_stream_forward():
+    """quant/common/stream_pipeline.py: consecutive batches alternate between two HIP streams (every workspace of the binding
+    and of the modules is per launch stream) -- the outputs are those of the plain forward bit for bit, in order, for the solving
+    (ls-2) and the chained 1-bit network, and `evaluate` reports the same metrics with it as without."""
+    import bench
+    from quant.common import training
+    from quant.common.metrics import LossMetric, Top1Accuracy
+    from quant.common.stream_pipeline import StreamPipeline
+    for arch, shape in ((bench.imagenet_arch('ls-2', 3), (6, 3, 224, 224)), (bench.cifar_arch(), (20, 3, 32, 32))):
+        model = bench.build_model(arch, DEV)
+        xs = [torch.randn(*shape, generator=torch.Generator().manual_seed(s)).to(DEV) for s in range(5)]
+        with torch.no_grad():
+            want = [model(x).clone() for x in xs]
+            pipe = StreamPipeline(model, DEV, 2)
+            assert pipe.depth == 2
+            got = [y.clone() for y in pipe.map(xs)]
+            torch.cuda.synchronize()
+        assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want))
+        targets = [torch.randint(0, want[0].shape[1], (shape[0],), generator=torch.Generator().manual_seed(9 + i)) for i in range(5)]
+
+        class Loader(list):
+            dataset = list(range(5 * shape[0]))
+
+        loader = Loader((x.cpu(), t) for x, t in zip(xs, targets))
+        res = {}
+        for streams in (1, 2):
+            old = training.eval_streams
+            training.eval_streams = lambda device, sharded=False, n=streams: n
+            try:
+                metrics = {'loss': LossMetric(torch.nn.functional.cross_entropy, True), 'top1': Top1Accuracy(True)}
+                res[streams] = training.evaluate(model, loader, metrics, DEV, 1)
+            finally:
+                training.eval_streams = old
+        assert res[1] == res[2], res
