@@ -330,13 +330,52 @@ class _Clock:
         return self.ev.elapsed_time(other.ev) if self.cuda else 1e3 * (other.t - self.t)
 
 
+def parity_probe(device):
+    """A live check that rides along with the numbers: one eval-mode QuantConv2d (ls-2 x ls-1, 64 -> 64, 3 x 3) on the kernels
+    against the CPU oracle -- v1 of the free-running solve bit-equal to the exact oracle, and with the GPU's scales injected
+    into the oracle the convolution within north_star's 1e-4 of max|y|.  The free-running deviation from the REFERENCE (its
+    fp32 argmin's tie-break) is the committed derivation's, quoted with its source."""
+    import glob
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import detgen
+    from oracle import lsq_exact, ref_port
+    from quant.binary.binary_conv import QuantConv2d
+    clamp = {'kind': 'symmetric', 'alpha': 3}
+    conv = QuantConv2d('ls-2', 'ls-1', 64, 64, 3, clamp, padding=1, bias=True)
+    detgen.fill_module(conv, seed=11)
+    x = detgen.normal('smoke.x', (4, 64, 14, 14), scale=1.2)
+    with torch.no_grad():
+        conv.w_approximate.v1.copy_(ref_port.weight_scales(conv.weight, 'ls-1')[0])
+        conv.eval().to(device)
+        y = conv(x.to(device)).cpu()
+        v = conv.last_act_scales.clone().cpu()
+        y_ref = ref_port.quant_conv2d(x, conv.weight.detach().cpu(), conv.bias.detach().cpu(), 'ls-2', 'ls-1',
+                                      [conv.w_approximate.v1.cpu()], clamp, 1, 1, x_scales=[v[0], v[1]])
+    err = float((y - y_ref).abs().max() / y_ref.abs().max())
+    exact = bool(np.array_equal(v[0].numpy(), lsq_exact.solve_rows(x.clamp(-3, 3).numpy(), False, 3)))
+    out = {'injected_scales': {'bound': 1e-4, 'observed_max_rel_err': err, 'met': err < 1e-4},
+           'solver_v1_equals_exact_oracle': exact}
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_free_running_parity.json')))
+    if files:
+        doc = json.load(open(files[-1]))
+        keys = ('conv_fixture', 'resnet_logits', 'fused_logits')          # one layer / whole network (ls-T: the worst) / fused blocks
+        out['free_running_vs_reference'] = {
+            'observed_of_max_abs': {k: round(doc['observed_max'][k], 6) for k in keys if k in doc.get('observed_max', {})},
+            'derived_limit': {k: round(doc['limits'][k], 6) for k in keys if k in doc.get('limits', {})},
+            'note': 'the reference\'s fp32 argmin decides near-tied candidates by rounding; the kernels equal the exact-arithmetic '
+                    'oracle bit for bit; limits derived on the CPU (tests/golden/make_free_limits.py)',
+            'source': 'profiles/' + os.path.basename(files[-1])}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--min-seconds', type=float, default=1.0,
-                    help='repeat the bracket of --steps timed steps until this much time has been timed')
+    ap.add_argument('--min-seconds', type=float, default=5.0,
+                    help='repeat the bracket of --steps timed steps until this much time has been timed (headline region)')
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--cpu-sample', type=int, default=256, help='batch of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -348,7 +387,9 @@ def main():
     ap.add_argument('--image-size', type=int, default=224, help='(plumbing checks only; the metric is quoted at 224)')
     ap.add_argument('--no-pin', action='store_true', help='do not pin the rank to the cores of its GPU\'s NUMA node')
     ap.add_argument('--streams', type=int, default=2,
-                    help='HIP streams consecutive steps alternate between in the second timed region (1: only the single-stream region)')
+                    help='HIP streams consecutive steps alternate between (quant.common.stream_pipeline, the product\'s evaluate path); '
+                         '1: one stream, every kernel alone on the chip -- what profiled runs pass')
+    ap.add_argument('--detail', default=None, help='write the per-kernel / per-layer-shape tables to this JSON file')
     args = ap.parse_args()
 
     from quant.common import rank_launcher
@@ -397,7 +438,8 @@ def main():
         world = dist.get_world_size()
 
     from quant import _hip
-    from quant.common.sharded_eval import all_gather_logits, evaluate_sharded
+    from quant.common.sharded_eval import all_gather_logits, local_forward
+    from quant.common.stream_pipeline import StreamPipeline
     arch = imagenet_arch(args.act, 3 if args.act == 'ls-2' else 2)
     model = build_model(arch, device)
     g = torch.Generator(device='cpu').manual_seed(rank)
@@ -405,119 +447,96 @@ def main():
     gathered = torch.empty((world * args.batch, 1000), dtype=torch.float32, device=device) if dist.is_initialized() else None
     in_group = dist.is_initialized()
     roofline = cuda and not args.no_roofline
+    nstreams = args.streams if cuda else 1
+    PATH_KERNELS = ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d')
 
-    def step():
-        # local forward + all-gather of logits (issued with one rank too when the process is one of a group)
-        return evaluate_sharded(model, x, gathered, always_collective=in_group)
+    def bracket(run, min_seconds):
+        """Repetitions of EXACTLY args.steps steps, each between barrier + synchronize on both sides, until at least
+        `min_seconds` have been timed; (seconds, repetitions, ms per step of every repetition), max over ranks per bracket."""
+        elapsed, reps, rep_ms = 0.0, 0, []
+        while True:
+            if world > 1:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            run(args.steps)
+            if world > 1:
+                dist.barrier()
+            sync()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())                           # (every rank sees the same dt: same number of repetitions)
+            elapsed += dt
+            reps += 1
+            rep_ms.append(1e3 * dt / args.steps)
+            if elapsed >= min_seconds or reps >= 10000:
+                return elapsed, reps, rep_ms
 
-    for _ in range(args.warmup):
-        step()
-    dominant = None
-    if roofline:
-        # one fully instrumented (untimed) step finds the dominant C-ABI kernel and the per-kernel table;
-        # inside the timed region only that kernel is bracketed with HIP events, and only in the first step of every
-        # group of steps (an event pair costs a few microseconds of stream time per call: ~0.3 ms per step if every
-        # call carried one, ~0.1 ms if every launch of the dominant kernel did)
+    # ---- the step as the product's evaluation loop issues it (quant.common.training.evaluate): the local forward of step i
+    # is queued on one of `nstreams` HIP streams (round robin) while the logits of step i - 1 are all-gathered on the main
+    # stream behind that forward's event.  nstreams = 1: everything on the one stream, every kernel alone on the chip.
+    pipe = StreamPipeline(lambda shard: local_forward(model, shard), device, nstreams)
+
+    def run_steps(n):
+        window = []
+
+        def consume():
+            y = window.pop(0).result()
+            if in_group:
+                all_gather_logits(y, gathered, always_collective=True)
+
+        for k in range(n):
+            window.append(pipe.submit(x))
+            if len(window) >= pipe.depth:
+                consume()
+        while window:
+            consume()
+
+    with torch.no_grad():
+        run_steps(max(args.warmup, 2 * nstreams))
         sync()
-        _hip.enable_timing(True)
-        step()
-        sync()
-        by_shape = _hip.drain_timing(by_tag=True)
-        table = {}
-        for (name, _tag), v in by_shape.items():
-            table[name] = tuple(a + b for a, b in zip(table.get(name, (0, 0.0, 0, 0, 0)), v))
-        candidates = {k: v for k, v in table.items() if k in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d')}
-        dominant = max(candidates, key=lambda k: candidates[k][1])
-        _hip.enable_timing(True, only=[dominant])
-    if world > 1:
-        dist.barrier()
-    sync()
-    # Repetitions of EXACTLY args.steps timed steps, each bracketed by barrier + synchronize on both sides; as many
-    # repetitions as it takes to time at least args.min_seconds (a 20-step bracket is 0.06 s: too short for the clocks
-    # and the power state to settle).  value = all timed steps / the sum of the brackets' times (max over ranks per
-    # bracket).  Events between groups of steps (none inside a step) give the per-step minimum / median.
-    per = max(1, args.steps // 10)
-    groups = [per] * (args.steps // per) + ([args.steps % per] if args.steps % per else [])
-    elapsed, reps, group_ms, rep_ms = 0.0, 0, [], []
-    while True:
-        if world > 1:
-            dist.barrier()
-        sync()
-        t0 = time.perf_counter()
-        marks = [_Clock(cuda)]
-        for i, n in enumerate(groups):
-            for k in range(n):
-                _hip.pause_timing(k != 0)
-                step()
-            marks.append(_Clock(cuda))
-        _hip.pause_timing(False)
-        if world > 1:
-            dist.barrier()
-        sync()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())                               # (every rank sees the same dt: same number of repetitions)
-        elapsed += dt
-        reps += 1
-        rep_ms.append(1e3 * dt / args.steps)
-        group_ms += [marks[i].ms_until(marks[i + 1]) / n for i, n in enumerate(groups)]
-        if elapsed >= args.min_seconds or reps >= 10000:
-            break
-    group_ms.sort()
+        elapsed, reps, rep_ms = bracket(run_steps, args.min_seconds)
     steps_timed = reps * args.steps
-    timed_table = _hip.drain_timing() if roofline else {}
-    _hip.enable_timing(False)
 
-    # ---- second timed region: the same steps, consecutive ones on alternating HIP streams (quant/common/stream_pipeline.py:
-    # what quant.common.training.evaluate does with consecutive batches).  Same bracket: EXACTLY args.steps steps between
-    # barrier + synchronize, repeated until args.min_seconds have been timed, max over ranks per bracket.  The all-gather
-    # of a step's logits stays on the one main stream, ordered after that step's forward.
-    piped = None
-    if cuda and args.streams > 1:
-        from quant.common.stream_pipeline import StreamPipeline
-        pipe = StreamPipeline(model, device, args.streams)
+    # ---- one stream: the reference point of rounds 1-4 and the region the per-kernel figures come from (each kernel alone on
+    # the chip, as in the rocprofv3 summaries under profiles/).  HIP events sit around the launches of the two path kernels in
+    # the first step of every group of steps only (an event pair costs a few microseconds of stream time).
+    single = None
+    table, by_shape, timed_table = {}, {}, {}
+    if nstreams > 1 or roofline:
+        one = StreamPipeline(lambda shard: local_forward(model, shard), device, 1)
 
-        def run_pipelined(n):
-            window = []
-
-            def consume():
-                y = window.pop(0).result()
+        def run_single(n, sample_every=0):
+            for k in range(n):
+                if sample_every:
+                    _hip.pause_timing(k % sample_every != 0)
+                y = one.submit(x).result()
                 if in_group:
                     all_gather_logits(y, gathered, always_collective=True)
-
-            for _ in range(n):
-                window.append(pipe.submit(x))
-                if len(window) >= pipe.depth:
-                    consume()
-            while window:
-                consume()
+            if sample_every:
+                _hip.pause_timing(False)
 
         with torch.no_grad():
-            run_pipelined(max(args.warmup, 2 * args.streams))
-            p_elapsed, p_reps, p_rep_ms = 0.0, 0, []
-            while True:
-                if world > 1:
-                    dist.barrier()
+            run_single(max(3, args.warmup // 2))
+            if roofline:
                 sync()
-                t0 = time.perf_counter()
-                run_pipelined(args.steps)
-                if world > 1:
-                    dist.barrier()
+                _hip.enable_timing(True)
+                run_single(1)                                     # one fully instrumented (untimed) step: the per-kernel table
                 sync()
-                dt = time.perf_counter() - t0
-                if world > 1:
-                    t = torch.tensor([dt], dtype=torch.float64, device=device)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    dt = float(t.item())
-                p_elapsed += dt
-                p_reps += 1
-                p_rep_ms.append(1e3 * dt / args.steps)
-                if p_elapsed >= args.min_seconds or p_reps >= 10000:
-                    break
-        piped = {'streams': args.streams, 'steps_timed': p_reps * args.steps, 'repetitions': p_reps, 'timed_seconds': p_elapsed,
-                 'ms_per_step': 1e3 * p_elapsed / (p_reps * args.steps), 'ms_per_step_best_repetition': min(p_rep_ms)}
+                by_shape = _hip.drain_timing(by_tag=True)
+                for (name, _tag), v in by_shape.items():
+                    table[name] = tuple(a + b for a, b in zip(table.get(name, (0, 0.0, 0, 0, 0)), v))
+                _hip.enable_timing(True, only=[k for k in PATH_KERNELS if k in table])
+            per = max(1, args.steps // 10)
+            s_elapsed, s_reps, s_rep_ms = bracket(lambda n: run_single(n, per if roofline else 0), min(args.min_seconds, 1.5))
+            if roofline:
+                timed_table = _hip.drain_timing()
+                _hip.enable_timing(False)
+        single = {'value': world * args.batch * s_reps * args.steps / s_elapsed, 'unit': 'images/sec', 'steps_timed': s_reps * args.steps,
+                  'timed_seconds': s_elapsed, 'ms_per_step': 1e3 * s_elapsed / (s_reps * args.steps),
+                  'ms_per_step_best_repetition': min(s_rep_ms)}
 
     allgather = None
     if in_group:
@@ -541,8 +560,7 @@ def main():
                      'allgather_GBps': recv / (us * 1e-6) / 1e9 if world > 1 else 0.0,
                      'per_link_GBps': recv / (us * 1e-6) / 1e9 / max(world - 1, 1) if world > 1 else 0.0,
                      'backend': dist.get_backend(), 'world_size_seen_by_backend': dist.get_world_size(),
-                     'note': ('RCCL' if cuda else 'gloo') + ' all_gather of fp32 logits, max over ranks, mean of 50 back-to-back calls; '
-                             'per_link = received bytes / (world - 1) point-to-point xGMI links'}
+                     'note': ('RCCL' if cuda else 'gloo') + ' all_gather of fp32 logits, max over ranks, mean of 50 back-to-back calls'}
 
     if rank == 0:
         value = world * args.batch * steps_timed / elapsed
@@ -552,78 +570,78 @@ def main():
             'value': value, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'steps_timed': steps_timed, 'repetitions': reps, 'timed_seconds': elapsed,
-            'ms_per_step': 1e3 * elapsed / steps_timed, 'ms_per_step_min': group_ms[0], 'ms_per_step_median': group_ms[len(group_ms) // 2],
-            'ms_per_step_best_repetition': min(rep_ms),
+            'ms_per_step': 1e3 * elapsed / steps_timed, 'ms_per_step_best_repetition': min(rep_ms),
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'i8 mfma on sign bits (exact integers) + f32', 'data': 'synthetic',
             'config': {'workload': f'ResNet-18 ImageNet ls-1 weight / {args.act} activation, '
                                    f'synthetic 3x{args.image_size}x{args.image_size}, batch {args.batch} per GPU, random-init weights',
-                       'global_batch': world * args.batch, 'parallelism': f'dp{world} (batch-sharded replicas, '
-                                                                          'RCCL all-gather of logits)'},
+                       'global_batch': world * args.batch,
+                       'parallelism': f'dp{world} (batch-sharded replicas, ' + ('RCCL' if cuda else 'gloo') + ' all-gather of logits)',
+                       'issue': (f'consecutive steps alternate between {nstreams} HIP streams, as quant.common.training.evaluate issues '
+                                 'consecutive batches; logits bit-identical to the one-stream forward') if nstreams > 1 else 'one HIP stream'},
             'launcher': {'kind': launcher, 'ranks': world, 'numa_pinning_rank0': pinned},
             'path_frac': value / world / PATH_ROOFLINE_IMG_S[args.act],
-            'path_frac_note': 'images/s per GPU / 628 k images/s = 8 TB/s over the 12.74 MB per image the 16 QuantConv2d '
-                              'layers read and write once (SURVEY 8(d)); popcount roofline 376 k images/s (ls-2)',
         }
-        if piped is not None:
-            # `value` keeps the definition of rounds 1-3: consecutive steps on ONE stream, every kernel alone on the chip -- what
-            # `roofline` and the rocprofv3 summaries under profiles/ describe.  The two-stream region is reported BESIDE it, not
-            # instead of it: a reader comparing this line with an earlier round's compares like with like.
-            pvalue = world * args.batch * piped['steps_timed'] / piped['timed_seconds']
-            piped.update(value=pvalue, unit='images/sec', vs_single_stream=pvalue / value,
-                         path_frac=pvalue / world / PATH_ROOFLINE_IMG_S[args.act],
-                         note=('the same steps with consecutive ones alternating between %d HIP streams (quant/common/stream_pipeline.py, '
-                               'what quant.common.training.evaluate does with consecutive batches): the dispatch ramp and the last tiles '
-                               'of one step\'s kernels run under the next step\'s kernels; logits bit-identical to the single-stream '
-                               'forward.  NOT the definition of `value` in this or any earlier round' % piped['streams']))
-            out['pipelined'] = piped
+        if nstreams > 1:
+            out['pipelined'] = {'streams': nstreams, 'value': value, 'ms_per_step': out['ms_per_step'],
+                                'vs_single_stream': value / single['value'] if single else None}
+        if single is not None:
+            out['single_stream'] = single
         if not cuda:
             out.update(device='cpu', dtype='f32 (torch formulation)',
                        note='PLUMBING CHECK of the launcher and the gloo collective on the host -- not a measurement of the HIP path')
-            out['config']['parallelism'] = f'dp{world} (batch-sharded replicas, gloo all-gather of logits)'
-        if roofline:
-            out['roofline'] = kernel_roofline(dominant, *timed_table[dominant], shapes=shapes_of(by_shape, dominant),
-                                              batch=args.batch)     # events over the timed region
-            launches, nbytes = timed_table[dominant][0], timed_table[dominant][2]
-            out['roofline']['measured'] = ('HIP events around every launch of this kernel in the first step of every group of '
-                                           '%d steps of the timed region (one stream: the kernel alone on the chip, as in the '
-                                           'rocprofv3 summaries under profiles/)' % per)
-            out['roofline']['traffic'] = None
-            pmc = pmc_traffic_per_launch(dominant, args.act) if args.batch == 256 and args.image_size == 224 else None
-            if pmc and 'stale' in pmc:
-                out['roofline']['traffic_note'] = pmc['stale']
-            elif pmc:
-                out['roofline']['traffic'] = pmc['bytes_per_launch']
-                out['roofline']['traffic_note'] = ('HBM bytes per launch (all kernels of one call), rocprofv3 PMC passes over this very '
-                                                   'workload in profiles/' + pmc['source'] + '; algorithmic bytes per launch = %.4g'
-                                                   % (nbytes / launches))
+        detail = {}
+        if roofline and table:
             kern = {}
-            for k, v in table.items():                                     # the instrumented step before the timed region
-                kern[k] = kernel_roofline(k, *v, shapes=shapes_of(by_shape, k), batch=args.batch)
-                kern[k]['ms_per_step'] = v[1]
-                kern[k]['launches_per_step'] = v[0]
+            for k, v in table.items():                                     # the instrumented step
+                tv = timed_table.get(k, v)                                 # path kernels: events over the timed region
+                e = kernel_roofline(k, *tv, shapes=shapes_of(by_shape, k), batch=args.batch)
+                e['ms_per_step'] = v[1]
+                e['launches_per_step'] = v[0]
+                e['algorithmic_bytes_per_launch'] = v[2] / max(v[0], 1)
+                e['traffic'] = e['traffic_ratio'] = None
                 p = pmc_traffic_per_launch(k, args.act) if args.batch == 256 and args.image_size == 224 else None
-                if p and 'stale' not in p:
-                    kern[k]['traffic'] = p['bytes_per_launch']
-                    kern[k]['algorithmic_bytes_per_launch'] = v[2] / max(v[0], 1)
-            # per layer shape: which launches are output-bound (HBM) and which matrix-core-bound
+                if p and 'stale' in p:
+                    e['traffic_note'] = p['stale']
+                elif p:
+                    e['traffic'] = p['bytes_per_launch']
+                    e['traffic_ratio'] = p['bytes_per_launch'] / e['algorithmic_bytes_per_launch']
+                    e['traffic_note'] = 'HBM bytes per launch, rocprofv3 PMC passes over this workload: profiles/' + p['source']
+                kern[k] = e
+            names = {'lsq_act_quant': 'quantizer', 'lsq_xnor_conv2d': 'xnor_conv', 'lsq_signw_conv2d': 'signw_conv'}
+            path = {names[k]: kern[k] for k in kern if k in names}
+            slim = lambda e: {kk: vv for kk, vv in e.items() if kk not in ('note', 'bytes', 'mfma_busy_note', 'secondary', 'traffic_note')}   # noqa: E731
+            worst = min(path, key=lambda k: path[k]['frac'])                # the path kernel furthest below ITS roofline
+            out['roofline'] = dict(slim(path[worst]), name=worst,
+                                   measured='one stream (each kernel alone on the chip, as in the rocprofv3 summaries under profiles/): HIP '
+                                            'events around every launch of the kernel in the first step of every group of steps of the '
+                                            'single_stream region; roofline = the path kernel with the lower fraction, both follow')
+            for k, e in path.items():
+                out['roofline'][k] = slim(e)
+                if 'secondary' in e:
+                    out['roofline'][k]['hbm_frac'] = e['secondary']['frac']
+            out['roofline']['other_kernels_ms_per_step'] = {k: round(v[1], 4) for k, v in table.items() if k not in names}
             shapes = {}
             for (name, tag), (cnt, ms, nb, ops, _sb) in sorted(by_shape.items(), key=lambda kv: str(kv[0])):
-                if tag is None or name not in ('lsq_act_quant', 'lsq_xnor_conv2d', 'lsq_signw_conv2d'):
+                if tag is None or name not in PATH_KERNELS:
                     continue
                 row = {'launches': cnt, 'avg_launch_us': 1e3 * ms / cnt, 'algorithmic_GBps': nb / (ms * 1e-3) / 1e9}
                 if ops:
                     row['T_binary_MAC_per_s' if name == 'lsq_xnor_conv2d' else 'TFLOP_per_s'] = ops / (ms * 1e-3) / 1e12
                 shapes.setdefault(name, {})[tag] = row
-            out['roofline']['kernels'] = kern
-            out['roofline']['by_layer_shape'] = shapes
-            out['roofline']['kernels_measured'] = 'one fully instrumented step after the warm-up'
+            detail['kernels'] = kern
+            detail['by_layer_shape'] = shapes
         if allgather is not None:
             out['allgather'] = allgather
+        if cuda and world == 1:
+            try:
+                out['parity'] = parity_probe(device)
+            except Exception as exc:                                       # (the numbers above stand without it; say what happened)
+                out['parity'] = {'error': repr(exc)[:200]}
         if cuda and args.cpu_sample > 0 and world == 1:
             out['cpu_baseline'] = cpu_baseline(arch, model, args.cpu_sample)
         if cuda and world == 1 and not args.no_configs and args.act == 'ls-2':
-            # the other single-GPU configurations BASELINE.json lists, as short legs of this process
+            # the other single-GPU configurations BASELINE.json lists, as short legs of this process (one stream, eager)
             cfg = {}
             # the north_star-literal __popcll XNOR kernel on the headline network, beside the int8-MFMA one above
             old = _hip.xnor_impl(True)
@@ -660,10 +678,20 @@ def main():
             xm = torch.randn(64, 1, 28, 28, generator=torch.Generator().manual_seed(0)).to(device)
             cfg['mnist_lenet_ls1w_fpa_b64'] = config_leg('lenet', m, xm, 200, 5, 'LeNet-5 mnist_ls1_weight_fp_activation, synthetic '
                                                          '1x28x28, batch 64', 19048.0, graph=True)
-            out['configs'] = cfg
-            out['configs_note'] = ('value = images/sec of the EAGER eval forward, inputs resident in HBM (graph_replay, where present, is a '
-                                   'separate figure); reference_cpu_images_per_sec_survey = the reference itself on the 8 '
-                                   'build-container cores (SURVEY section 6)')
+            detail['configs'] = cfg
+            # the line carries the legs' headline figures; their kernel tables go to --detail
+            out['configs'] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()
+                                  if kk in ('batch', 'value', 'ms_per_step', 'launch', 'reference_cpu_images_per_sec_survey')}
+                              for k, v in cfg.items()}
+            for k, v in cfg.items():
+                if 'graph_replay' in v:
+                    out['configs'][k]['graph_replay_value'] = round(v['graph_replay']['value'], 1)
+            out['configs_note'] = 'one stream, eager eval forward, images/sec, inputs resident in HBM; full tables: --detail'
+        if args.detail and detail:
+            detail['line'] = out
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, 'w') as f:
+                json.dump(detail, f, indent=1)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist.is_initialized():

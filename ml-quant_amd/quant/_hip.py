@@ -505,11 +505,23 @@ def stem_overflow_check(device) -> bool:
     return st['tripped']
 
 
-def stem_overflow_reset(device) -> None:
-    """Forget an earlier report (after the caller has dealt with it); waits for the device."""
+def stem_overflow_flag_raised(device) -> bool:
+    """True while the DEVICE flag is up, i.e. a call since the last ``stem_overflow_reset`` saw an out-of-domain operand
+    (``stem_overflow_check`` also reports a trip that was dealt with earlier).  Waits for the device."""
+    st = _stem_guard_state(device)
+    torch.cuda.synchronize(device)
+    st['event'] = None
+    raised = int(st['flag'].item()) != 0
+    st['tripped'] = st['tripped'] or raised
+    return raised
+
+
+def stem_overflow_reset(device, keep_tripped: bool = False) -> None:
+    """Forget an earlier report (after the caller has dealt with it); waits for the device.  ``keep_tripped``: lower the
+    device flag but keep the host-side memory of it, so that callers stay on the bf16 split (``evaluate`` repeats a pass)."""
     torch.cuda.synchronize(device)
     st = _stem_guard_state(device)
-    st['event'], st['tripped'], st['calls'] = None, False, 0
+    st['event'], st['tripped'], st['calls'] = None, bool(keep_tripped and st['tripped']), 0
     st['flag'].zero_()
     st['host'].zero_()
 

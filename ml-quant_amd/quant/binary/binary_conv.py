@@ -197,7 +197,8 @@ class QuantConv2d(nn.Conv2d):
 
     def fused_forward(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
                       res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
-                      prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None) -> torch.Tensor:
+                      prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None,
+                      res_ready: Optional[torch.cuda.Event] = None) -> torch.Tensor:
         """``act(self(pre_bn(x)) + res_pre) + res_post`` -- one residual-block half (quant/models/resnet.py:
         95-100, 182-190); ``act`` = ReLU (``relu=True``), PReLU (``prelu`` = the nn.PReLU weight) or identity.
         On the HIP path the eval-mode batch norm is folded into the quantizer's read and the non-linearity /
@@ -206,7 +207,11 @@ class QuantConv2d(nn.Conv2d):
         if self._wants_hip(x) and (pre_bn is None or (not pre_bn.training and pre_bn.track_running_stats)):
             # next_q = (batch norm or None, QuantConv2d) that will consume the result: with 1-bit activations on both
             # sides the consumer's quantizer runs in THIS convolution's epilogue (quant.binary.chain)
-            return self._forward_hip(x, pre_bn, relu, res_pre, res_post, prelu, next_q)
+            # res_ready: the residual operands were produced on another stream (the projection shortcut, models/resnet.py);
+            # the quantizer does not need them, the convolution's launch waits for the event
+            return self._forward_hip(x, pre_bn, relu, res_pre, res_post, prelu, next_q, res_ready)
+        if res_ready is not None:
+            torch.cuda.current_stream(x.device).wait_event(res_ready)
         y = self(x if pre_bn is None else pre_bn(x))
         if res_pre is not None:
             y = y + res_pre
@@ -296,7 +301,8 @@ class QuantConv2d(nn.Conv2d):
 
     def _forward_hip(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
                      res_pre: Optional[torch.Tensor] = None, res_post: Optional[torch.Tensor] = None,
-                     prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None) -> torch.Tensor:
+                     prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None,
+                     res_ready: Optional[torch.cuda.Event] = None) -> torch.Tensor:
         from quant import _hip
         from quant.binary import chain
         handed = chain.pending(x)                  # (an attribute of the tensor object: read before detach())
@@ -312,7 +318,11 @@ class QuantConv2d(nn.Conv2d):
         ho, wo = _hip.out_hw(geom)
         y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
         bias = None if self.bias is None else self.bias.detach()
+        def join():                      # residual operands from a side stream: in front of the convolution, behind the quantizer
+            if res_ready is not None:
+                torch.cuda.current_stream(x.device).wait_event(res_ready)
         if self.x_quant == 'fp':
+            join()
             _hip.signw_conv2d(x, self._alpha(), wbits, wscales, bias, geom, y, pre, relu, res_pre, res_post, prelu, wprep)
             return y
         xq = self.x_approximate
@@ -331,6 +341,7 @@ class QuantConv2d(nn.Conv2d):
                     planes_in, units_in = handed.planes, handed.units
                 else:
                     planes_in, scales_in = self._act_planes(x, geom, k, n, pre, xq, _hip)
+                join()
                 if _hip.xnor_conv2d_chain(planes_in, scales_in, units_in, self._alpha(), wbits, wsum, wscales, bias, geom, y,
                                           relu, res_pre, res_post, prelu, None if target is None else target[0]):
                     self.last_act_scales = scales_in          # (None when the scale came from the producer's row sums)
@@ -342,6 +353,7 @@ class QuantConv2d(nn.Conv2d):
                     self.last_act_scales = scales_in
                     return y
         planes, scales = self._act_planes(x, geom, k, n, pre, xq, _hip)
+        join()
         _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)
         self.last_act_scales = scales
         return y

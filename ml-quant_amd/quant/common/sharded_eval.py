@@ -67,6 +67,16 @@ def all_gather_logits(local: torch.Tensor, out: Optional[torch.Tensor] = None, g
 
 
 @torch.no_grad()
+def local_forward(model: torch.nn.Module, x_local: torch.Tensor) -> torch.Tensor:
+    """This rank's logits for its shard -- the half of :func:`evaluate_sharded` in front of the collective (the evaluation
+    loop queues it on a side stream and all-gathers on its own).  An empty shard: see :func:`evaluate_sharded`."""
+    if x_local.shape[0] == 0:
+        probe = model(x_local.new_zeros((1,) + tuple(x_local.shape[1:])))
+        return probe[:0]
+    return model(x_local)
+
+
+@torch.no_grad()
 def evaluate_sharded(model: torch.nn.Module, x_local: torch.Tensor, out: Optional[torch.Tensor] = None,
                      group=None, total: Optional[int] = None, always_collective: bool = False) -> torch.Tensor:
     """One inference step: local forward on this rank's shard, then the all-gather of logits.
@@ -75,9 +85,4 @@ def evaluate_sharded(model: torch.nn.Module, x_local: torch.Tensor, out: Optiona
     shard): the kernels refuse empty batches, and a rank that raised would leave the others waiting in the
     collective -- such a rank runs the model on ONE sample borrowed from its own padding (zeros of the input's
     shape), to learn the width of the logits, and contributes no rows."""
-    if x_local.shape[0] == 0:
-        probe = model(x_local.new_zeros((1,) + tuple(x_local.shape[1:])))
-        local = probe[:0]
-    else:
-        local = model(x_local)
-    return all_gather_logits(local, out, group, total, always_collective)
+    return all_gather_logits(local_forward(model, x_local), out, group, total, always_collective)

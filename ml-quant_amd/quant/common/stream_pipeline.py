@@ -50,6 +50,7 @@ class StreamPipeline:
         if self.device.type == 'cuda' and streams > 1:
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(streams)]
         self._next = 0
+        self._last_done: Optional[torch.cuda.Event] = None
 
     @property
     def depth(self) -> int:
@@ -63,9 +64,17 @@ class StreamPipeline:
         side = self.streams[self._next % len(self.streams)]
         self._next += 1
         side.wait_event(cur.record_event())
+        if self._next <= len(self.streams) and self._last_done is not None:
+            # The first forward on EACH stream runs behind the forward submitted before it: a model that was just built,
+            # loaded or trained fills its module-level caches (packed weight planes, prepared sign weights, folded batch norms:
+            # keyed by tensor version, not by stream) on the first stream, and a second stream that got a host-side cache hit
+            # would read those buffers with nothing ordering it after the writes.  From the second round on every cache is
+            # warm and the streams run free.
+            side.wait_event(self._last_done)
         with torch.cuda.stream(side):
             out = self.model(x)
             done = side.record_event()
+        self._last_done = done
         if isinstance(x, torch.Tensor):
             x.record_stream(side)
         return Pending(out, done, self.device)
@@ -82,6 +91,7 @@ class StreamPipeline:
 
 
 def eval_streams(device, sharded: bool = False) -> int:
-    """Streams ``evaluate`` uses: two on a GPU, one on the CPU or when the batch is sharded over ranks (the logits'
-    all-gather is a collective on ONE stream per communicator)."""
-    return 2 if torch.device(device).type == 'cuda' and not sharded else 1
+    """Streams ``evaluate`` uses: two on a GPU -- also when the batch is sharded over ranks: the local forwards alternate
+    between the two streams and the logits' all-gather stays on the caller's stream, behind the forward's event, in the same
+    order on every rank (round 5; until then a sharded evaluation dropped to one stream) --, one on the CPU."""
+    return 2 if torch.device(device).type == 'cuda' else 1

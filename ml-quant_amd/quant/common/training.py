@@ -20,7 +20,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from quant.common.metrics import Metric
-from quant.common.sharded_eval import evaluate_sharded, local_slice
+from quant.common.sharded_eval import all_gather_logits, local_forward, local_slice
 from quant.common.stream_pipeline import StreamPipeline, eval_streams
 
 logger = logging.getLogger(__name__)
@@ -28,7 +28,7 @@ Hook = Callable[..., None]
 
 
 def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: torch.device, epoch: int,
-             hooks: Optional[Sequence[Hook]] = None) -> Dict[str, float]:
+             hooks: Optional[Sequence[Hook]] = None, _retry: bool = False) -> Dict[str, float]:
     """Evaluate ``model`` on ``test_loader``; returns {metric name: value}."""
     hooks = hooks or []
     model.eval()
@@ -37,14 +37,18 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
     sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     batch_idx = -1
     # consecutive batches alternate between two HIP streams (stream_pipeline.py: the dispatch ramp and the last tiles of one
-    # forward's kernels run under the other forward's kernels); the metrics of batch i - 1 are taken on THIS stream while
-    # batch i runs.  One stream on the CPU and for sharded batches: same order of operations as the reference's loop.
-    pipe = StreamPipeline(model, device, eval_streams(device, sharded))
+    # forward's kernels run under the other forward's kernels); the metrics of batch i - 1 -- and, when the batch is sharded
+    # over ranks, the all-gather of its logits -- are taken on THIS stream while batch i runs.  Every rank submits and
+    # consumes in the same order, so the collectives line up.  One stream on the CPU: the reference's order of operations.
+    pipe = StreamPipeline(lambda shard: local_forward(model, shard) if sharded else model(shard), device,
+                          eval_streams(device, sharded))
     window = []
 
     def consume():
-        pending, target = window.pop(0)
+        pending, target, total = window.pop(0)
         output = pending.result()
+        if sharded:
+            output = all_gather_logits(output, total=total)
         for metric in metrics.values():
             metric.update(output, target)
 
@@ -53,23 +57,25 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
             target = target.to(device)
             if sharded:
                 # the shard is cut on the host: only this rank's samples cross PCIe
-                part = local_slice(data.shape[0], dist.get_rank(), dist.get_world_size())
-                output = evaluate_sharded(model, data[part].to(device), total=data.shape[0])
-                for metric in metrics.values():
-                    metric.update(output, target)
-                continue
-            window.append((pipe.submit(data.to(device)), target))
+                data = data[local_slice(data.shape[0], dist.get_rank(), dist.get_world_size())]
+            window.append((pipe.submit(data.to(device)), target, target.shape[0]))
             if len(window) >= pipe.depth:
                 consume()
         while window:
             consume()
-    for hook in hooks:
-        hook(epoch=epoch, global_step=1 + (epoch - 1) * len(test_loader.dataset) + batch_idx)
     if torch.device(device).type == 'cuda':
         from quant import _hip
-        if _hip.available() and _hip.stem_overflow_check(device):
-            logger.warning('lsq_stem_conv_pool saw operands at or beyond 65504 during this evaluation: those batches were '
-                           'computed on saturated operands; the stem has switched to the bf16 split')
+        if _hip.available() and _hip.stem_overflow_flag_raised(device):
+            # batches of this pass were computed on saturated stem operands (inf / nan logits): the stem has switched to the
+            # bf16 split, which takes any finite input -- the whole pass is repeated on it instead of reporting those metrics
+            if not _retry:
+                logger.warning('lsq_stem_conv_pool saw operands at or beyond 65504 during this evaluation; repeating it with '
+                               'the bf16 split of the stem')
+                _hip.stem_overflow_reset(device, keep_tripped=True)
+                return evaluate(model, test_loader, metrics, device, epoch, hooks, _retry=True)
+            logger.warning('lsq_stem_conv_pool: the flag is still raised after the repeated evaluation (non-finite input?)')
+    for hook in hooks:
+        hook(epoch=epoch, global_step=1 + (epoch - 1) * len(test_loader.dataset) + batch_idx)
     computed = {name: metric.compute() for name, metric in metrics.items()}
     logger.info('Test set evaluation metrics:')
     for name, metric in metrics.items():

@@ -217,22 +217,51 @@ class XnorBasicBlock(nn.Module):
         if _fusable(self, x):
             # eval on the GPU: bn -> quantizer and conv -> relu -> (+shortcut) each collapse into one
             # kernel pair (QuantConv2d.fused_forward); same arithmetic as the modular path below
-            sc = self.shortcut(x)
+            sc, sc_ready = _shortcut_on_side_stream(self.shortcut, x)
             a1, a2 = _act_args(self.nonlin1), _act_args(self.nonlin2)
             # next_q: who quantizes the result next -- with 1-bit activations that quantizer runs in the producing
             # convolution's epilogue (quant.binary.chain); `chain_next` = the following block's (bn1, conv1), set by QResNet
             nxt = self.__dict__.get('chain_next')
             if self.double_shortcut:
-                first = self.conv1.fused_forward(x, self.bn1, res_post=sc, next_q=(self.bn2, self.conv2), **a1)
+                first = self.conv1.fused_forward(x, self.bn1, res_post=sc, next_q=(self.bn2, self.conv2), res_ready=sc_ready, **a1)
                 return self.conv2.fused_forward(first, self.bn2, res_post=first, next_q=nxt, **a2)
             first = self.conv1.fused_forward(x, self.bn1, next_q=(self.bn2, self.conv2), **a1)
-            return self.conv2.fused_forward(first, self.bn2, res_pre=sc, next_q=nxt, **a2)
+            return self.conv2.fused_forward(first, self.bn2, res_pre=sc, next_q=nxt, res_ready=sc_ready, **a2)
         first = self.nonlin1(self.conv1(self.bn1(x)))
         if self.double_shortcut:
             first = first + self.shortcut(x)
             return self.nonlin2(self.conv2(self.bn2(first))) + first
         second = self.conv2(self.bn2(first)) + self.shortcut(x)
         return self.nonlin2(second)
+
+
+#: the projection shortcut (1x1 stride-2 convolution + batch norm, resnet.py:180-190 of the reference) does not depend on the
+#: block's main branch: it runs on a side stream under the block's first quantizer and joins in front of the convolution whose
+#: epilogue adds it (False: in line on the caller's stream, as the reference's forward orders it)
+SIDE_STREAM_SHORTCUT = False
+_SIDE_STREAMS: Dict = {}
+
+
+def _shortcut_on_side_stream(shortcut: nn.Module, x: torch.Tensor):
+    """(shortcut(x), event or None): a projection is queued on the side stream that belongs to the caller's current stream,
+    ordered after everything queued so far (``x`` is ready); the returned event marks its end and the convolution that adds
+    the result waits for it (``QuantConv2d.fused_forward(res_ready=...)``).  Identity shortcuts and graph capture: in line."""
+    if (not SIDE_STREAM_SHORTCUT or len(shortcut) == 0 or not x.is_cuda or torch.cuda.is_current_stream_capturing()):
+        return shortcut(x), None
+    cur = torch.cuda.current_stream(x.device)
+    key = (x.device.index, cur.cuda_stream)
+    side = _SIDE_STREAMS.get(key)
+    if side is None:
+        if len(_SIDE_STREAMS) >= 64:
+            _SIDE_STREAMS.clear()
+        side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=x.device)
+    side.wait_event(cur.record_event())
+    with torch.cuda.stream(side):
+        sc = shortcut(x)
+        ready = side.record_event()
+    x.record_stream(side)             # (the allocator must not hand x's block out while the side stream reads it)
+    sc.record_stream(cur)             # (allocated on the side stream, consumed on the caller's)
+    return sc, ready
 
 
 def _fusable(block: nn.Module, x: torch.Tensor) -> bool:

@@ -7,8 +7,8 @@
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 tag=${1:-r03}; o=gpurun_out
 mkdir -p $o
-python bench.py > $o/${tag}_bench_n1_ls2.json 2> $o/bench_ls2.err
-python bench.py --act fp --no-configs > $o/${tag}_bench_n1_fpact.json 2> $o/bench_fp.err
+python bench.py --detail $o/${tag}_bench_n1_ls2_detail.json > $o/${tag}_bench_n1_ls2.json 2> $o/bench_ls2.err
+python bench.py --act fp --no-configs --detail $o/${tag}_bench_n1_fpact_detail.json > $o/${tag}_bench_n1_fpact.json 2> $o/bench_fp.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 \
   --steps 100 --cpu-sample 0 --no-configs > $o/${tag}_bench_torchrun_n1_ls2.json 2> $o/bench_torchrun.err
 rm -rf $o/prof_final

@@ -44,7 +44,7 @@ def timed(nstreams, steps=60):
 
 with torch.no_grad():
     ref = [model(x).clone() for x in xs]
-    for n in (1, 2, 3):
+    for n in ([int(v) for v in sys.argv[2:]] or (1, 2, 3)):
         ms, outs = timed(n)
         same = all(torch.equal(o, r) for o, r in zip(outs, ref))
         print(f'{act}: {n} stream(s): {ms:.3f} ms per batch of 256 ({256 / ms * 1e3:.0f} images/s); logits as on one stream: {same}')

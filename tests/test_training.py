@@ -19,7 +19,7 @@ def test_train_runs_the_reference_loop_on_cpu():
     from quant.models.lenet import QLeNet5
     torch.manual_seed(3)
     model = QLeNet5(loss_fn=torch.nn.functional.nll_loss, x_quant='ls-2', w_quant='ls-1', clamp={'kind': 'symmetric', 'alpha': 2})
-    loader = MNISTDataLoader(train_batch_size=32, test_batch_size=32, dataset_path='', workers=0, n_test=96).get_train_loader()
+    loader = MNISTDataLoader(train_batch_size=32, test_batch_size=32, dataset_path='', workers=0, n_train=96).get_train_loader()
     opt = get_optimizer(model.parameters(), {'algorithm': 'sgd', 'lr': 0.05, 'momentum': 0.9})
     sched = get_lr_scheduler(opt, {'scheduler': 'step_lr', 'step_size': 1, 'gamma': 0.5}, epochs=2, steps_per_epoch=len(loader))
     seen = []
