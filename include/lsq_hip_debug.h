@@ -24,7 +24,9 @@ extern "C" {
 int lsq_debug_xnor_impl(int popcount_only);
 /* 1: lsq_act_quant / lsq_solve_rows take the streaming three-kernel path for every shape (default 0) */
 int lsq_debug_force_streaming(int on);
-/* single-launch quantizer: 1 = every flagged bin through its block path, 2 = key list of 2048 entries (default 0) */
+/* single-launch quantizer, bit mask (default 0): 1 = every flagged bin of the round-2 solve through its block path, 2 = its
+ * key list holds 2048 entries, 4 = no windowed level-1 histogram (the round-2 solve alone, as for rows without a symmetric
+ * clamp), 8 = windowed histogram built, then every row handed to the fall-back (the call into the round-2 body) */
 int lsq_debug_fused_mode(int mode);
 
 /* device buffer of one int32 per row (sized by the caller for its largest batch; NULL = off, the default): every

@@ -19,7 +19,10 @@ struct FusedArgs {
   float* scales;            // [2][N]
   int N;
   int ternary;
-  int debug;                // developer / test switches: 1 every flagged bin through the block path, 2 a 2048-key list
+  int debug;                // developer / test switches: 1 every flagged bin through the block path, 2 a 2048-key list,
+                            // 4 no windowed level-1 histogram (the round-2..4 solve only), 8 windowed histogram built, then dropped
+  unsigned win_k0;          // windowed level-1 histogram (set by fused_act_quant): fine bin of key k >= win_k0 is
+  int win_sh;               // (k - win_k0) >> win_sh, 8192 bins up to the top of the clamp value's binade; 0: off
   const float* forced;      // [2][N] scales given by the caller (moving-average inference): no solve, planes only
   int* trace;               // test hook: chosen sorted position per row (lsq_debug_solver_trace), or null
   int greedy;               // gf-2 (quantization.py:118-148 with k = 2): v1 = mean |x| instead of the solve; planes and

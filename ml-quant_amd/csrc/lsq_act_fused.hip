@@ -34,16 +34,24 @@
 // closed-form cost, same argmin); scripts/fused_vs_streaming.py and tests/test_gpu_parity.py check it, the rare
 // paths included (lsq_debug_fused_mode).
 
+#include <cstring>
 #include <type_traits>
 
 #include "lsq_act_fused.h"
 #include "lsq_solver_math.h"
 
+#ifndef LSQ_WIN_HIST
+#define LSQ_WIN_HIST 0
+#endif
 namespace lsq {
 #ifdef LSQ_PHASE_CLOCKS
 __device__ long long g_fused_times[1024][16];    // constant-rate clock (100 MHz) at the phase marks of each workgroup
 #define FMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_fused_times[blockIdx.x][i] = (long long)wall_clock64(); } while (0)
+__device__ int g_win_stats[1024][4];             // windowed level 1: 1 solved / 2 fell back, flags, flagged groups, flagged fine bins
+#define WSTAT(p, f, g, s) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_win_stats[blockIdx.x][0] = (p); g_win_stats[blockIdx.x][1] = (int)(f); \
+  g_win_stats[blockIdx.x][2] = (int)(g); g_win_stats[blockIdx.x][3] = (int)(s); } } while (0)
 #else
+#define WSTAT(p, f, g, s) do {} while (0)
 #define FMARK(i) do {} while (0)
 #endif
 namespace {
@@ -59,6 +67,10 @@ constexpr int kSeg3 = 8;
 constexpr int kBlkSlots = 8;                   // flagged level-1 bins the block path histograms per read of the row
 constexpr unsigned kTaskBit = 0x8000u;
 constexpr int kBnCap = 1024;                   // channels whose folded batch norm is staged in LDS
+constexpr int kWinSlots = 32;                  // windowed level 1: flagged fine bins (each one brute-force task)
+constexpr int kWinTask = 128;                  // keys a flagged fine bin may hold (two per lane of the wave that ranks them)
+constexpr int kWinGroups = 24;                 // windowed level 1: flagged groups of 16 fine bins
+constexpr int kLowBins = 256;                  // windowed level 1: one bin per binade for the keys below the window
 
 struct Node {
   unsigned prefix, cnt, r0, cell;   // key >> (31 - bits); keys; sorted position in front; successor cell
@@ -74,6 +86,14 @@ struct Task {
 };
 struct Seg3 {
   unsigned pref, next_pref, cnt, r0;
+  double p0;
+};
+struct WGroup {                     // a flagged group of 16 fine bins: the lane that owns it, rank and prefix sum in front
+  unsigned lane, r0;
+  double p0;
+};
+struct WSlot {                      // a flagged fine bin
+  unsigned bin, cnt, r0, pad;
   double p0;
 };
 
@@ -118,17 +138,35 @@ struct FixedLds {
 static constexpr int kRefineFixed = 2 * L1_BINS + 8 + kNodeCap * 64 * 12 + kArena * 4;   // role, succ, nhist, centry, arena
 static constexpr int kListCap = ((160 * 1024 - (int)sizeof(FixedLds) - kRefineFixed) / 4) & ~63;   // keys of the flagged bins
 
+struct WinLds {                                     // windowed level 1 (solve_windowed): lives where the scan tables of the
+  unsigned long long hist_low[kLowBins];           // round-2 solve live (that solve rebuilds everything it reads)
+  unsigned short role[L1_BINS + 2];                // fine bin -> low byte: slot + 1; high byte: slot + 1 of the flagged bin whose
+                                                   // successor bin this is; [L1_BINS] = 0 for keys outside the window
+  unsigned arena[kWinSlots][kWinTask];             // keys of the flagged fine bins
+  unsigned fill[kWinSlots], succ[kWinSlots];       // keys captured; smallest key above the bin
+  WGroup group[kWinGroups];
+  WSlot slot[kWinSlots];
+  unsigned n_groups, n_slots, flags, pad0;
+  WSlot run;                                       // the bin of the row's largest key when it is a run of that key (pad = 1)
+  unsigned first_bin[kWaves];                      // per wave: its lowest non-empty fine bin
+  double wl[kWaves];                               // inclusive low-region sums of the block scan
+};
 struct FusedLds : FixedLds {
   union {
     struct {                                       // pass 1 and the level-1 scan(s); blk: block path
       unsigned long long hist1[L1_BINS];
-      unsigned short nzlist[L1_BINS];
       union {
         struct {
-          unsigned nz_r0[kNzCap];
-          double nz_p0[kNzCap];
+          unsigned short nzlist[L1_BINS];
+          union {
+            struct {
+              unsigned nz_r0[kNzCap];
+              double nz_p0[kNzCap];
+            };
+            BlockHists blk;                        // (the level-1 scan's prefix tables are dead between scans)
+          };
         };
-        BlockHists blk;                            // (the level-1 scan's prefix tables are dead between scans)
+        WinLds w;
       };
     } a;
     struct {                                       // on-chip refinement
@@ -910,6 +948,404 @@ static __device__ __forceinline__ Best refine_resident(FusedLds* lds, unsigned n
   return best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Windowed level 1 (round 5).  Under a symmetric clamp every key is at most key(alpha), and the rows of a network sit in the
+// few binades below it: the 13 histogram bits are spent on a WINDOW of key space -- fine bin of key k >= k0 is (k - k0) >> sh,
+// 8192 bins up to the top of alpha's binade (sh = 13: 1024 bins per binade over 8 binades; sh = 14: 512 over 16) -- instead
+// of 32 bins per binade over all 254.  A bin still never straddles a binade (k0 is a multiple of 2^sh, 2^sh divides 2^23),
+// so its sum is the same exact integer arithmetic (bin_sum_exact); the keys below the window are counted in one bin per
+// binade (exact sums again).  With bins sixteen to thirty-two times finer the bins that can hold a candidate
+// (optimal.py:78-80) hold a few dozen keys at most: each is ONE brute-force task, captured straight out of the key
+// registers -- no key list, no node histograms, no refinement rounds: level-1 scan, group test, fine test, one sweep over
+// the registers, one wave per flagged bin, argmin.  Anything the fixed tables cannot take -- a candidate possible below the
+// window, a flagged fine bin with more than 64 keys that is not a run of the row's largest key, more than kWinGroups /
+// kWinSlots flagged -- makes solve_windowed return false BEFORE it has touched the key registers, and the caller rebuilds
+// the 32-bins-per-binade histogram from them and runs the round-2 solve (solve_from_hist): same candidates, same argmin.
+static __device__ __forceinline__ void hist_add_win(FusedLds* lds, unsigned key, unsigned k0, int sh, unsigned low_base) {
+#if LSQ_WIN_HIST == 1
+  // one atomic per key, its address and operand selected (a branch per key costs more than the selects)
+  const unsigned t = key - k0;
+  const bool in = key >= k0;
+  const unsigned idx = in ? t >> sh : low_base + (key >> 23);
+  const unsigned low = in ? (t & ((1u << sh) - 1u)) : (key & 0x7FFFFFu);
+  atomicAdd(&lds->a.hist1[idx], kOne | (unsigned long long)low);
+#else
+  if (key >= k0) {
+    const unsigned t = key - k0;
+    atomicAdd(&lds->a.hist1[t >> sh], kOne | (unsigned long long)(t & ((1u << sh) - 1u)));
+  } else {                                       // below the window (rare): one bin per binade, the 23 mantissa bits summed
+    atomicAdd(&lds->a.hist1[low_base + (key >> 23)], kOne | (unsigned long long)(key & 0x7FFFFFu));
+  }
+#endif
+}
+
+// One wave resolves a flagged fine bin: its <= 128 captured keys (two per lane beyond 64) are ranked from LDS broadcast reads,
+// every position is tested exactly (optimal.py:78-80) and costed in closed form -- resolve_task's arithmetic on the windowed
+// tables.
+static __device__ __forceinline__ void resolve_wslot(FusedLds* lds, unsigned n, unsigned s, bool ternary, Best& best) {
+  const int lane = threadIdx.x & 63;
+  const double total = lds->total;
+  const WSlot sl = lds->a.w.slot[s];
+  const unsigned cc = sl.cnt, rs = sl.r0;
+  const double ps = sl.p0;
+  unsigned* const wk = lds->a.w.arena[s];
+  const unsigned succ_k = lds->a.w.succ[s];
+  struct R {
+    unsigned key, rank, below, eq;
+    double bsum, psum;
+  };
+  auto rank_of = [&](unsigned idx) {             // key `idx` of the bin against all of them
+    R r;
+    r.key = idx < cc ? wk[idx] : kNoKey;
+    r.rank = r.below = r.eq = 0u;
+    r.bsum = r.psum = 0.0;
+    for (unsigned j0 = 0; j0 < cc; j0 += 4u) {
+      unsigned kj[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kj[q] = j0 + (unsigned)q < cc ? wk[j0 + (unsigned)q] : kNoKey;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned j = j0 + (unsigned)q;
+        const double vj = (double)key_value(kj[q]);
+        const bool lt = kj[q] < r.key, e = kj[q] == r.key;
+        r.below += lt ? 1u : 0u;
+        r.eq += e ? 1u : 0u;
+        if (lt) r.bsum += vj;
+        if (lt || (e && j <= idx)) r.psum += vj;
+        if (lt || (e && j < idx)) ++r.rank;
+      }
+    }
+    return r;
+  };
+  auto test = [&](const R& r, unsigned idx) {    // (after the keys were rewritten in sorted order)
+    if (idx >= cc) return;
+    const unsigned nk = r.rank + 1u < cc ? wk[r.rank + 1u] : succ_k;
+    const double v = (double)key_value(r.key);
+    const double nv = nk != kNoKey ? (double)key_value(nk) : INFINITY;
+    const long long i = (long long)rs + r.rank;
+    const bool cand = i >= 1 && i <= (long long)n - 2 &&
+                      position_is_candidate(v, nv, (double)(i + 1), ps + r.psum, (double)n, total, ternary);
+    if (cand) {
+      Best cb;
+      cb.cost = cost_of(v, rs + r.below, ps + r.bsum, r.eq, n, total, ternary);
+      cb.order = rs + r.below;
+      cb.value = key_value(r.key);
+      if (better(cb, best)) best = cb;
+    }
+  };
+  const R r0 = rank_of((unsigned)lane);
+  if (cc <= (unsigned)kWave) {                   // (uniform)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if ((unsigned)lane < cc) wk[r0.rank] = r0.key;            // sorted order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    test(r0, (unsigned)lane);
+  } else {
+    const R r1 = rank_of((unsigned)lane + (unsigned)kWave);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    wk[r0.rank] = r0.key;
+    if ((unsigned)lane + (unsigned)kWave < cc) wk[r1.rank] = r1.key;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    test(r0, (unsigned)lane);
+    test(r1, (unsigned)lane + (unsigned)kWave);
+  }
+}
+
+// Part 1 (S1-S3): from the windowed histogram to the slot records of the flagged fine bins; false when the row is the
+// round-2 solve's.  The key registers are not touched (they stay live in the caller: loops rolled, state in LDS).
+static __device__ __forceinline__ bool win_plan(FusedLds* lds, unsigned n, unsigned minkey, unsigned maxkey, bool ternary) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned k0 = lds->args.win_k0;
+  const int sh = lds->args.win_sh;
+  const unsigned lowmask = (1u << sh) - 1u;
+  const unsigned long long* const hist = lds->a.hist1;
+  WinLds& w = lds->a.w;
+  constexpr unsigned BPL = L1_BINS / kThreads;                 // fine bins per lane = one group
+  static_assert(BPL == 16, "a group is one DPP row of the fine test");
+  // ---- S1: every lane sums ITS group of 16 consecutive fine bins (bin order), lanes 0..255 one low bin each; block scan
+  // (a lane's 16 bins are 128 bytes apart from its neighbour's: read in the same order by every lane that is a 32-way bank
+  //  conflict; lane L starts at bin (L >> 1) & 15 of its group and wraps around -- 32 lanes, 32 different bank pairs.  The
+  //  order of the fp64 additions inside a group is then the lane's own, fixed, order: the terms are exact, the sum is
+  //  the same number on every run)
+  unsigned gc = 0, first = kNoKey;
+  double gs = 0.0;
+#pragma unroll 4
+  for (unsigned uu = 0; uu < BPL; ++uu) {
+    const unsigned u = (uu + ((unsigned)tid >> 1)) & (BPL - 1u);
+    const unsigned b = (unsigned)tid * BPL + u;
+    const unsigned long long h = hist[b];
+    const unsigned c = (unsigned)(h >> 42);
+    if (c) {
+      gs += bin_sum_exact(k0 + (b << sh), c, h & kLowMask);
+      gc += c;
+      first = min(first, b);
+    }
+  }
+  unsigned lc = 0;
+  double ls = 0.0;
+  if (tid < kLowBins) {
+    const unsigned long long h = w.hist_low[tid];
+    lc = (unsigned)(h >> 42);
+    if (lc) ls = bin_sum_exact((unsigned)tid << 23, lc, h & kLowMask);
+  }
+  const unsigned igc = wave_incl_scan(gc), ilc = wave_incl_scan(lc);
+  const double igs = wave_incl_scan(gs), ils = wave_incl_scan(ls);
+  const unsigned first_own = first;
+  first = wave_min(first);
+  if (lane == 63) {
+    lds->wa[wid] = igc;
+    lds->wb[wid] = ilc;
+    lds->ws[wid] = igs;
+    w.wl[wid] = ils;
+  }
+  if (lane == 0) {
+    w.first_bin[wid] = first;
+  }
+  lds_barrier();
+  unsigned ogc = 0, tgc = 0, tlc = 0, fbin = kNoKey;
+  double ogs = 0.0, tgs = 0.0, tls = 0.0;
+  for (int q = 0; q < kWaves; ++q) {
+    if (q == wid) {
+      ogc = tgc;
+      ogs = tgs;
+    }
+    tgc += lds->wa[q];
+    tlc += lds->wb[q];
+    tgs += lds->ws[q];
+    tls += w.wl[q];
+    fbin = min(fbin, w.first_bin[q]);
+  }
+  const unsigned r0g = tlc + ogc + (igc - gc);                 // keys in front of this lane's group
+  const double p0g = tls + (ogs + (igs - gs));                 // and their sum
+  const double total = tls + tgs;
+  if (tid == 0) lds->total = total;
+  FMARK(2);
+  // ---- S2: the conservative test on whole groups (and, by the last lane, on everything below the window)
+  // the first non-empty fine bin ABOVE this lane's group bounds the first key above the group: the lowest non-empty bin of
+  // the lanes above it in the wave (suffix minimum over the lanes), else of the waves above
+  unsigned nfb;
+  {
+    unsigned sfx = gc ? first_own : kNoKey;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = (unsigned)__shfl_down((int)sfx, d);
+      if (lane + d < 64) sfx = min(sfx, o);
+    }
+    const unsigned up1 = (unsigned)__shfl_down((int)sfx, 1);
+    nfb = lane < 63 ? up1 : kNoKey;
+    for (int q = wid + 1; q < kWaves; ++q) nfb = min(nfb, w.first_bin[q]);
+  }
+  if (gc && n >= 3u) {
+    const unsigned b0 = (unsigned)tid * BPL;
+    const double vlo = (double)key_value(k0 + (b0 << sh));
+    const double vhi = (double)key_value(k0 + ((b0 + BPL) << sh) - 1u);
+    // (no bin above: the group holds the row's largest key, and the test does not look at next_hi)
+    const double next_hi = nfb != kNoKey ? (double)key_value(k0 + ((nfb + 1u) << sh) - 1u) : vhi;
+    if (may_hold_candidate(r0g, gc, p0g, gs, vlo, vhi, next_hi, n, total, ternary)) {
+      const unsigned gi = atomicAdd(&w.n_groups, 1u);
+      if (gi < (unsigned)kWinGroups) {
+        WGroup g;
+        g.lane = (unsigned)tid;
+        g.r0 = r0g;
+        g.p0 = p0g;
+        w.group[gi] = g;
+      }
+    }
+  }
+  if (tid == kThreads - 1 && tlc && n >= 3u) {
+    // the keys below the window as ONE bin: [smallest key, largest key below k0]; the first key above them is the smallest
+    // key of the lowest non-empty fine bin (at most that bin's upper edge and its mean)
+    const double vlo = (double)key_value(minkey);
+    const double vhi = (double)key_value(min(k0 - 1u, maxkey));
+    double next_hi = vhi;
+    if (fbin != kNoKey) {
+      const unsigned long long h2 = hist[fbin];
+      const unsigned c2 = (unsigned)(h2 >> 42);
+      const double edge = (double)key_value(k0 + ((fbin + 1u) << sh) - 1u);
+      const double mean = quick_div(bin_sum_exact(k0 + (fbin << sh), c2, h2 & kLowMask), (double)c2) * (1.0 + 1e-12);
+      next_hi = mean < edge ? mean : edge;
+    }
+    if (may_hold_candidate(0u, tlc, 0.0, tls, vlo, vhi, next_hi, n, total, ternary)) atomicOr(&w.flags, 1u);
+  }
+  lds_barrier();
+  FMARK(3);
+  // (readfirstlane: values read from LDS are divergent as far as the compiler knows, and a divergent exit here is turned into
+  //  predicated regions that keep pass 2's early request alive -- as zeros -- across the fall-back: scratch on both paths)
+  const unsigned ngr = (unsigned)__builtin_amdgcn_readfirstlane((int)w.n_groups);
+  const unsigned fl2 = (unsigned)__builtin_amdgcn_readfirstlane((int)(w.flags | (unsigned)(lds->args.debug & 8)));
+  if (ngr > (unsigned)kWinGroups || (fl2 & 9u)) {
+    WSTAT(2, w.flags, ngr, 0);
+    return false;
+  }
+  // ---- S3: the fine bins of the flagged groups, one lane each (a group = one DPP row of 16 lanes)
+  {
+    const unsigned gi = (unsigned)tid >> 4, bi = (unsigned)tid & 15u;
+    const bool act = gi < ngr;
+    WGroup g;
+    g.lane = 0u;
+    g.r0 = 0u;
+    g.p0 = 0.0;
+    unsigned bin = 0u, c = 0u;
+    unsigned long long h = 0ull;
+    double sm = 0.0;
+    if (act) {
+      g = w.group[gi];
+      bin = g.lane * BPL + bi;
+      h = hist[bin];
+      c = (unsigned)(h >> 42);
+      if (c) sm = bin_sum_exact(k0 + (bin << sh), c, h & kLowMask);
+    }
+    unsigned ic = c;                                           // inclusive scan inside the row (all lanes execute the moves)
+    ic += dpp_or_zero<0x111, 0xF>(ic);
+    ic += dpp_or_zero<0x112, 0xF>(ic);
+    ic += dpp_or_zero<0x114, 0xF>(ic);
+    ic += dpp_or_zero<0x118, 0xF>(ic);
+    double is = sm;
+    is += dpp_or_zero<0x111, 0xF>(is);
+    is += dpp_or_zero<0x112, 0xF>(is);
+    is += dpp_or_zero<0x114, 0xF>(is);
+    is += dpp_or_zero<0x118, 0xF>(is);
+    if (act && c) {
+      const unsigned r0 = g.r0 + (ic - c);
+      const double p0 = g.p0 + (is - sm);
+      unsigned nb = bin + 1u;                                  // the next non-empty fine bin (usually the very next)
+      unsigned long long h2 = 0ull;
+      while (nb < (unsigned)L1_BINS) {
+        h2 = hist[nb];
+        if (h2 >> 42) break;
+        ++nb;
+      }
+      const double vlo = (double)key_value(k0 + (bin << sh));
+      const double vhi = (double)key_value(k0 + ((bin + 1u) << sh) - 1u);
+      double next_hi = vhi;
+      if (nb < (unsigned)L1_BINS) {
+        const unsigned c2 = (unsigned)(h2 >> 42);
+        const double edge = (double)key_value(k0 + ((nb + 1u) << sh) - 1u);
+        const double mean = quick_div(bin_sum_exact(k0 + (nb << sh), c2, h2 & kLowMask), (double)c2) * (1.0 + 1e-12);
+        next_hi = mean < edge ? mean : edge;
+      }
+      if (may_hold_candidate(r0, c, p0, sm, vlo, vhi, next_hi, n, total, ternary)) {
+        if (c <= (unsigned)kWinTask) {
+          const unsigned sidx = atomicAdd(&w.n_slots, 1u);
+          if (sidx < (unsigned)kWinSlots) {
+            WSlot sl;
+            sl.bin = bin;
+            sl.cnt = c;
+            sl.r0 = r0;
+            sl.pad = 0u;
+            sl.p0 = p0;
+            w.slot[sidx] = sl;
+            w.fill[sidx] = 0u;
+            w.succ[sidx] = kNoKey;
+            reinterpret_cast<unsigned char*>(&w.role[bin])[0] = (unsigned char)(sidx + 1u);
+            if (nb < (unsigned)L1_BINS) reinterpret_cast<unsigned char*>(&w.role[nb])[1] = (unsigned char)(sidx + 1u);
+          }
+        } else if (maxkey >= k0 && bin == ((maxkey - k0) >> sh) &&
+                   (h & kLowMask) == (unsigned long long)c * (unsigned long long)((maxkey - k0) & lowmask)) {
+          // hundreds to thousands of copies of the clamp value: the bin of the row's largest key holds nothing above it, so
+          // its low-bit sum equals c * low(maxkey) exactly when all its keys ARE that key: one analytic run, no keys needed.
+          // Evaluated behind the key sweep (run_has_candidate is a CALL: with the keys live, half of them would be saved to
+          // scratch around it).
+          WSlot sl;
+          sl.bin = bin;
+          sl.cnt = c;
+          sl.r0 = r0;
+          sl.pad = 1u;
+          sl.p0 = p0;
+          w.run = sl;
+        } else {
+          atomicOr(&w.flags, 2u);                              // more keys than a task takes: the round-2 solve takes the row
+        }
+      }
+    }
+  }
+  lds_barrier();
+  FMARK(4);
+  const unsigned ns = (unsigned)__builtin_amdgcn_readfirstlane((int)w.n_slots);
+  const unsigned fl3 = (unsigned)__builtin_amdgcn_readfirstlane((int)w.flags);
+  if (ns > (unsigned)kWinSlots || (fl3 & 2u)) {
+    WSTAT(2, w.flags | 16u, ngr, ns);
+    return false;
+  }
+  WSTAT(1, fl3, ngr, ns);
+  return true;
+}
+
+// Part 2 (S4-S5): the keys of the flagged fine bins out of the registers, one wave per bin.  Only run when win_plan said
+// yes: the early request of pass 2 (keys_dead) is DEFINED here and nowhere else -- a join of this path with the fall-back's
+// (which still holds all the keys) would have both register sets live at once, and the allocator then homes the request in
+// scratch and waits for every one of its loads.
+template <int NK, class Early>
+static __device__ __forceinline__ void win_sweep(FusedLds* lds, unsigned n, unsigned maxkey, bool ternary,
+                                                 const unsigned (&kreg)[NK], Early keys_dead, Best& best) {
+  const int tid = threadIdx.x, wid = tid >> 6;
+  const unsigned k0 = lds->args.win_k0;
+  const int sh = lds->args.win_sh;
+  WinLds& w = lds->a.w;
+  const unsigned ns = (unsigned)__builtin_amdgcn_readfirstlane((int)w.n_slots);
+  // ---- S4: one sweep over the key registers, 16 at a time: table look-ups (independent loads), the rare hits captured into
+  // their bin's arena / folded into the successor minimum.  Pass 2's early loads take the registers over group by group.
+  constexpr int G = 16;
+#pragma unroll
+  for (int g0 = 0; g0 < NK; g0 += G) {
+    unsigned ent[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (g0 + g < NK) ent[g] = w.role[min((kreg[g0 + g] - k0) >> sh, (unsigned)L1_BINS)];   // (below the window / padding: wraps past the table)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g0 + g < NK) {
+        if (ent[g] != 0u) {
+          const unsigned key = kreg[g0 + g];
+          const unsigned own = ent[g] & 0xFFu, below = ent[g] >> 8;
+          if (own) {
+            const unsigned pos = atomicAdd(&w.fill[own - 1u], 1u);
+            w.arena[own - 1u][pos & (unsigned)(kWinTask - 1)] = key;
+          }
+          if (below && key < w.succ[below - 1u]) atomicMin(&w.succ[below - 1u], key);   // (the plain read spares most of the atomics)
+        }
+      }
+    }
+    {
+      constexpr int NG = (NK + G - 1) / G;
+      const int gi = g0 / G;
+      unsigned parts = 0;
+#pragma unroll
+      for (int k = 0; k < kPfParts; ++k)
+        if (k * NG / kPfParts == gi) parts |= 1u << k;
+      if (parts) keys_dead(parts);
+    }
+  }
+  lds_barrier();
+  FMARK(5);
+  FMARK(6);
+  FMARK(7);
+  // ---- S5: one wave per flagged fine bin
+  for (unsigned s = (unsigned)wid; s < ns; s += kWaves) resolve_wslot(lds, n, s, ternary, best);
+  if (tid == kThreads - 1 && w.run.pad) {                      // (the last wave has the fewest slots)
+    const WSlot sl = w.run;
+    const double v = (double)key_value(maxkey);
+    bool hit;
+    [[clang::always_inline]] hit = run_has_candidate(v, sl.cnt, sl.r0, sl.p0, INFINITY, n, lds->total, ternary);   // (a call here
+    // would save the early request's registers to scratch around it)
+    if (hit) {
+      Best cb;
+      cb.cost = cost_of(v, sl.r0, sl.p0, sl.cnt, n, lds->total, ternary);
+      cb.order = sl.r0;
+      cb.value = key_value(maxkey);
+      if (better(cb, best)) best = cb;
+    }
+  }
+  FMARK(8);
+#ifdef LSQ_PHASE_CLOCKS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_fused_times[blockIdx.x][11] = g_fused_times[blockIdx.x][12] = g_fused_times[blockIdx.x][8];
+    g_fused_times[blockIdx.x][13] = 0;
+    g_fused_times[blockIdx.x][14] = ns;
+    g_fused_times[blockIdx.x][15] = ns;
+  }
+#endif
+}
+
 // block argmin (first minimum in sorted order, optimal.py:151) -> lds->v1
 static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -939,6 +1375,23 @@ static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
     }
   }
   lds_barrier();
+}
+
+// The ternary scheme's extra candidate (optimal.py:86-118: min > mean / 2 adds mean / 2), then the block argmin -> v1.
+static __device__ __forceinline__ float finish_best(FusedLds* lds, unsigned n, unsigned minkey, bool ternary, Best best) {
+  if (ternary && n > 0u && threadIdx.x == 0) {
+    const double mean = lds->total / (double)n;
+    if ((double)key_value(minkey) > 0.5 * mean) {
+      const float half = (float)((double)((float)mean) / 2.0);
+      Best c;
+      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, lds->total, true);
+      c.order = n + 1u;
+      c.value = half;
+      if (better(c, best)) best = c;
+    }
+  }
+  block_argmin(lds, best);
+  return lds->v1;
 }
 
 // Everything between the level-1 histogram and v1.  `each_key` as in refine_resident.
@@ -989,20 +1442,7 @@ static __device__ __forceinline__ float solve_from_hist(FusedLds* lds, const flo
     early_drop();
   }
   early_ok = requested;
-  // ternary: min > mean/2 adds mean/2 (optimal.py:86-118)
-  if (ternary && n > 0u && tid == 0) {
-    const double mean = lds->total / (double)n;
-    if ((double)key_value(minkey) > 0.5 * mean) {
-      const float half = (float)((double)((float)mean) / 2.0);
-      Best c;
-      c.cost = cost_of((double)half, 0u, 0.0, 0u, n, lds->total, true);
-      c.order = n + 1u;
-      c.value = half;
-      if (better(c, best)) best = c;
-    }
-  }
-  block_argmin(lds, best);
-  return lds->v1;
+  return finish_best(lds, n, minkey, ternary, best);
 }
 
 static __device__ __forceinline__ void block_minmax(unsigned& mn, unsigned& mx, FusedLds* lds) {
@@ -1297,13 +1737,23 @@ static __device__ __forceinline__ double pass2_any(const FusedArgs& a, const flo
 // level-1 histogram, the keys kept in registers.  Solve.  Pass 2 = lane = VEC pixels x 64 channels sweep that
 // packs both planes and sums |x - v1 b1| (quantization.py:84-92, :112-115); for the short rows this second
 // read is served by the L2 / Infinity Cache the first one filled.
-template <int U, int VEC>
+template <int U, int VEC, bool WIN>
 static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
   const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
   FMARK(0);
   for (int i = tid; i < L1_BINS; i += kThreads) lds->a.hist1[i] = 0ull;
+  // windowed level-1 histogram (solve_windowed): fine bins over the binades below the clamp value, one bin per binade below them
+  constexpr bool win = WIN;                      // (the host launches the WIN kernels exactly when it has set a window)
+  const unsigned win_k0 = a.win_k0;
+  const int win_sh = a.win_sh;
+  const unsigned low_base = (unsigned)(lds->a.w.hist_low - lds->a.hist1);
+  if (win) {
+    for (int i = tid; i < kLowBins; i += kThreads) lds->a.w.hist_low[i] = 0ull;
+    for (int i = tid; i < (L1_BINS + 2) / 2; i += kThreads) reinterpret_cast<unsigned*>(lds->a.w.role)[i] = 0u;
+    if (tid == 0) lds->a.w.n_groups = lds->a.w.n_slots = lds->a.w.flags = lds->a.w.run.pad = 0u;
+  }
   if (tid == 0) lds->args = a;
   if (a.pre_scale != nullptr && a.C <= kBnCap) {
     for (int i = tid; i < a.C; i += kThreads) {
@@ -1385,7 +1835,8 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
             const bool has = jt < ntrip && (long long)e0 + 3 * e < M;
             const unsigned key = abs_key(clamp_sym(xs[e], a.alpha));
             if (has) {
-              hist_add(lds, key);
+              if (win) hist_add_win(lds, key, win_k0, win_sh, low_base);
+              else hist_add(lds, key);
               mk = min(mk, key);
               xk = max(xk, key);
             }
@@ -1403,51 +1854,88 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   // The first 128 floats of the lane's first pass-2 item are requested as soon as the refinement has copied the keys
   // it needs out of the registers (the usual path; rows that take the block path load them in pass 2 as before).
   const bool full = (a.cg & 63) == 0 && a.C <= kBnCap;
+  unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
+  unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
+  auto finish_row = [&](double acc, float v1) {
+    const double tot = block_sum(acc, lds);
+    FMARK(10);
+    if (tid == 0) {
+      a.scales[row] = v1;
+      a.scales[(long long)a.N + row] = ternary ? v1 : (float)(tot / (double)M);
+      if (a.trace) a.trace[row] = (int)lds->best_order;
+    }
+  };
+  auto pass2_late = [&](float v1) {              // pass 2 without an early request
+    if (full)
+      return affine ? pass2_full<VEC, true, false>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads)
+                    : pass2_full<VEC, false, false>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads);
+    return pass2_any<VEC>(a, xrow, v1, prow0, prow1, tid, kThreads);
+  };
   Pf<VEC> pf;
-  bool have_pf = false;
-  const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, maxkey, ternary, kreg, [&](unsigned parts) {
+  auto keys_dead = [&](unsigned parts) {
 #ifndef LSQ_NO_EARLY
     if (full) pass2_request<VEC>(a, xrow, tid, pf, parts);
 #endif
-  }, [&]() {
-#pragma unroll
-    for (int b = 0; b < Pf<VEC>::PB; ++b)
-#pragma unroll
-      for (int u = 0; u < Pf<VEC>::UB; ++u)
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) pf.v[b][u][v] = 0.f;
-  }, have_pf);
-  have_pf = have_pf && full;
+  };
+  auto pass2_early = [&](float v1, bool have_pf) {   // pass 2 whose first loads went out during the solve
 #ifdef LSQ_NO_EARLY
-  have_pf = false;
+    have_pf = false;
 #endif
-
-  FMARK(9);
-  // pass 2: both planes and sum |x - v1 b1|
-  unsigned long long* __restrict__ prow0 = a.planes + (long long)row * a.row_words;
-  unsigned long long* __restrict__ prow1 = prow0 + a.plane_words;
-  double acc;
-  if (full) {
-    acc = affine ? pass2_full<VEC, true, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads, &pf, have_pf)
-                 : pass2_full<VEC, false, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads, &pf, have_pf);
+    if (full)
+      return affine ? pass2_full<VEC, true, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads, &pf, have_pf)
+                    : pass2_full<VEC, false, true>(a, lds->bn_s, lds->bn_t, xrow, v1, prow0, prow1, tid, kThreads, &pf, have_pf);
+    return pass2_any<VEC>(a, xrow, v1, prow0, prow1, tid, kThreads);
+  };
+  if constexpr (WIN) {
+    Best best;
+    best.cost = INFINITY;
+    best.order = kNoKey;
+    best.value = 0.f;
+    if (tid == 0) lds->maxkey = maxkey;
+    // (readfirstlane: the compiler must SEE that the whole workgroup takes the same side -- a divergent branch becomes two
+    //  predicated regions with everything of both sides live across them)
+    if (__builtin_amdgcn_readfirstlane((int)win_plan(lds, n, minkey, maxkey, ternary)) != 0) {
+      win_sweep<4 * U>(lds, n, maxkey, ternary, kreg, keys_dead, best);
+      const float v1 = finish_best(lds, n, minkey, ternary, best);
+      FMARK(9);
+      finish_row(pass2_early(v1, true), v1);
+    } else {
+      // The row is the round-2 solve's, from its first load on, as a CALL: in line, its code -- which holds the keys far
+      // longer -- raises the register pressure of the whole function and the early request of the windowed path ends up
+      // in scratch (every early load then waited for).  The row is read once more, from L2 / Infinity Cache; rows that end
+      // here are rare (scripts/win_stats_net.py counts them).
+      run_round2<U, VEC>(lds);
+    }
   } else {
-    acc = pass2_any<VEC>(a, xrow, v1, prow0, prow1, tid, kThreads);
+    bool have_pf = false;
+    const float v1 = solve_from_hist<4 * U>(lds, xrow, n, minkey, maxkey, ternary, kreg, keys_dead, [&]() {
+#pragma unroll
+      for (int b = 0; b < Pf<VEC>::PB; ++b)
+#pragma unroll
+        for (int u = 0; u < Pf<VEC>::UB; ++u)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pf.v[b][u][v] = 0.f;
+    }, have_pf);
+    FMARK(9);
+    finish_row(pass2_early(v1, have_pf), v1);
   }
-  const double tot = block_sum(acc, lds);
-  FMARK(10);
-  if (tid == 0) {
-    a.scales[row] = v1;
-    a.scales[(long long)a.N + row] = ternary ? v1 : (float)(tot / (double)M);
-    if (a.trace) a.trace[row] = (int)lds->best_order;
-  }
+}
+// the round-2 kernel body as a function of its own (the windowed kernels' fall-back, see run)
+template <int U, int VEC>
+static __device__ __attribute__((noinline)) void run_round2(FusedLds* lds) {
+  const FusedArgs a = lds->args;                 // (the kernel's own argument block must not escape: it would live in scratch)
+  lds_barrier();                                 // every wave has left the windowed tables (and read the arguments)
+  run<U, VEC, false>(a, lds);
 }
 };  // struct Impl
 
-template <int T, int U, int VEC>
+// WIN: windowed level-1 histogram (solve_windowed) with the round-2 solve as the fall-back of single rows; !WIN: the
+// round-2 solve alone (rows without a symmetric clamp, lsq_debug_fused_mode 4)
+template <int T, int U, int VEC, bool WIN>
 __global__ __launch_bounds__(T) void aq_fused_kernel(FusedArgs a) {
   using I = Impl<T>;
   __shared__ __attribute__((aligned(16))) unsigned char smem[sizeof(typename I::FusedLds)];
-  I::template run<U, VEC>(a, reinterpret_cast<typename I::FusedLds*>(smem));
+  I::template run<U, VEC, WIN>(a, reinterpret_cast<typename I::FusedLds*>(smem));
 }
 
 // Scales given by the caller (moving-average inference modes, activation_quantization.py:90-98: the deployment
@@ -1595,20 +2083,44 @@ int launch_forced(const FusedArgs& a, int vec, hipStream_t st) {
 template <int T, int U>
 int launch(const FusedArgs& a, int vec, hipStream_t st) {
 #ifdef LSQ_DEV_VEC      // developer builds: one instantiation only (register-pressure experiments compile in seconds)
-  hipLaunchKernelGGL((aq_fused_kernel<T, U, LSQ_DEV_VEC>), dim3(a.N), dim3(T), 0, st, a);
+#ifdef LSQ_DEV_NOWIN
+  hipLaunchKernelGGL((aq_fused_kernel<T, U, LSQ_DEV_VEC, false>), dim3(a.N), dim3(T), 0, st, a);
 #else
-  if (vec == 4) hipLaunchKernelGGL((aq_fused_kernel<T, U, 4>), dim3(a.N), dim3(T), 0, st, a);
-  else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2>), dim3(a.N), dim3(T), 0, st, a);
-  else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1>), dim3(a.N), dim3(T), 0, st, a);
+  hipLaunchKernelGGL((aq_fused_kernel<T, U, LSQ_DEV_VEC, true>), dim3(a.N), dim3(T), 0, st, a);
+#endif
+#else
+  if (a.win_sh) {
+    if (vec == 4) hipLaunchKernelGGL((aq_fused_kernel<T, U, 4, true>), dim3(a.N), dim3(T), 0, st, a);
+    else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2, true>), dim3(a.N), dim3(T), 0, st, a);
+    else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1, true>), dim3(a.N), dim3(T), 0, st, a);
+  } else {
+    if (vec == 4) hipLaunchKernelGGL((aq_fused_kernel<T, U, 4, false>), dim3(a.N), dim3(T), 0, st, a);
+    else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2, false>), dim3(a.N), dim3(T), 0, st, a);
+    else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1, false>), dim3(a.N), dim3(T), 0, st, a);
+  }
 #endif
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int fused_act_quant(const FusedArgs& a, hipStream_t st) {
+int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
+  FusedArgs a = a_in;
   const long long HW = (long long)a.H * a.W;
   const long long M = a.row_elems;
+  // windowed level-1 histogram of the solve (solve_windowed): under a symmetric clamp every key is at most key(alpha), so the
+  // 8192 bins cover the binades below the top of alpha's binade -- 1024 bins per binade over 8 binades for long rows (a
+  // flagged bin must hold at most 64 keys), 512 over 16 for short ones; k0 = 0 when alpha's binade is that low already
+  a.win_k0 = 0u;
+  a.win_sh = 0;
+  if (a.alpha > 0.f && a.alpha < INFINITY && !(a.debug & 4) && !a.forced && !a.greedy) {
+    unsigned ka;
+    memcpy(&ka, &a.alpha, 4);
+    const int sh = (M + 2) / 3 >= 16384 ? 13 : 14;
+    const unsigned long long ktop = (unsigned long long)((ka >> 23) + 1u) << 23, span = (unsigned long long)L1_BINS << sh;
+    a.win_k0 = ktop > span ? (unsigned)(ktop - span) : 0u;
+    a.win_sh = sh;
+  }
   if (M + 2 >= (1ll << 31) || M % 4 != 0 || HW < 4 || ((uintptr_t)a.x % 16) != 0) return kFusedNotEligible;
   constexpr int T = 512;
   // pass 2, pixels per lane (measured on the four ResNet-18 shapes, scripts/kbench.py under LSQ_FUSED_VEC): four
@@ -1647,6 +2159,9 @@ int fused_act_quant(const FusedArgs& a, hipStream_t st) {
 #ifdef LSQ_PHASE_CLOCKS
 extern "C" int lsq_debug_read_fused_times(long long* host16384) {
   return (int)hipMemcpyFromSymbol(host16384, HIP_SYMBOL(g_fused_times), 16384 * sizeof(long long));
+}
+extern "C" int lsq_debug_read_win_stats(int* host4096) {
+  return (int)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(g_win_stats), 4096 * sizeof(int));
 }
 #endif
 

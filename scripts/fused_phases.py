@@ -26,10 +26,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--dist', default='gauss')
+    ap.add_argument('--shapes', default='', help='e.g. 256x14,512x7 (default: the four ResNet-18 shapes)')
+    ap.add_argument('--mode', type=int, default=0, help='lsq_debug_fused_mode')
     args = ap.parse_args()
     lib = _hip.lib()
     n = args.batch
-    for c, h in SHAPES:
+    shapes = [tuple(int(v) for v in t.split('x')) for t in args.shapes.split(',')] if args.shapes else SHAPES
+    lib.lsq_debug_fused_mode(args.mode)
+    for c, h in shapes:
         x = torch.randn(n, c, h, h, device='cuda')
         if args.dist != 'gauss':
             x = x.clamp(min=0)

@@ -50,7 +50,7 @@ def test_stream_pipeline_is_a_plain_call_on_the_cpu():
     model = torch.nn.Linear(4, 3)
     pipe = StreamPipeline(model, 'cpu', 2)
     xs = [torch.randn(5, 4, generator=torch.Generator().manual_seed(i)) for i in range(4)]
-    assert pipe.depth == 1 and eval_streams('cpu') == 1 and eval_streams('cuda', sharded=True) == 1 and eval_streams('cuda') == 2
+    assert pipe.depth == 1 and eval_streams('cpu') == 1 and eval_streams('cuda', sharded=True) == 2 and eval_streams('cuda') == 2
     with torch.no_grad():
         got = list(pipe.map(xs))
         assert all(torch.equal(g, model(x)) for g, x in zip(got, xs))

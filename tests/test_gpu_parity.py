@@ -300,8 +300,11 @@ def _fused_cases():
 @pytest.mark.parametrize('ternary', [False, True])
 def test_fused_quantizer_equals_exact_oracle_and_streaming_path(ternary):
     """The single-launch quantizer against oracle/lsq_exact.py (v1 bit-equal), the plane chain, and the streaming
-    three-kernel path (everything bit-equal), with its rare paths forced as well: mode 1 = every flagged bin
-    through the block path, mode 2 = a 2048-key list (most bins overflow)."""
+    three-kernel path (everything bit-equal), with its other paths forced as well (lsq_debug_fused_mode): 0 = as shipped
+    (round 5: windowed level-1 histogram under a clamp, the round-2 solve as the fall-back of single rows), 4 = the round-2
+    solve alone, 4 + 1 = every flagged bin through its block path, 4 + 2 = a 2048-key list (most bins overflow),
+    8 = windowed histogram built, then every row handed to the fall-back (the call into the round-2 body), 8 + 1 = the
+    fall-back through its block path."""
     hip = _hip()
     scheme = 3 if ternary else 2
     for tag, (arr, alpha) in _fused_cases().items():
@@ -311,7 +314,8 @@ def test_fused_quantizer_equals_exact_oracle_and_streaming_path(ternary):
         xc = x if alpha < 0 else x.clamp(-alpha, alpha)
         exact = E.solve_rows(xc.reshape(n, -1).numpy(), ternary, 3)
         results = {}
-        for name, force, mode in (('fused', 0, 0), ('block', 0, 1), ('small-list', 0, 2), ('streaming', 1, 0)):
+        for name, force, mode in (('fused', 0, 0), ('round2', 0, 4), ('block', 0, 5), ('small-list', 0, 6), ('dropped', 0, 8),
+                                  ('dropped-block', 0, 9), ('streaming', 1, 0)):
             with hip.debug_switches(force_streaming=force, fused_mode=mode):
                 results[name] = run_act_quant(x, scheme, 2, alpha, 1, pad)
         planes, scales = results['fused']
@@ -321,7 +325,7 @@ def test_fused_quantizer_equals_exact_oracle_and_streaming_path(ternary):
         if not ternary:
             v2 = P.quant_ls2(xc, scales[0])[1]
             assert torch.allclose(scales[1], v2, rtol=2e-6, atol=1e-12), tag
-        for name in ('block', 'small-list', 'streaming'):
+        for name in ('round2', 'block', 'small-list', 'dropped', 'dropped-block', 'streaming'):
             p2, s2 = results[name]
             assert np.array_equal(s2[0].numpy(), scales[0].numpy()), (tag, name)
             assert torch.allclose(s2[1], scales[1], rtol=1e-6, atol=0), (tag, name)     # fp32 partial sums over other channel subsets, fp64 above

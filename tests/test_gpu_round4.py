@@ -83,14 +83,17 @@ def test_chosen_candidate_position_on_device(golden, ternary, skip):
         x = rows.view(rows.shape[0], 1, 4, m // 4).contiguous()
         geom = hip.make_geom(x.shape[0], 1, 4, m // 4, 1, 1, 1, (1, 1), (0, 0), (1, 1), 1)
         words = hip.act_plane_words(geom)
-        for mode in (0, 1, 2):
+        # (a clamp above every value changes no key and switches the windowed level-1 histogram of round 5 on: mode 0 with it
+        #  = windowed solve with its natural fall-backs, mode 8 = every row through the fall-back call)
+        loose = max(1.0, 1.5 * float(rows.abs().max()))
+        for mode, alpha in ((0, -1.0), (1, -1.0), (2, -1.0), (0, loose), (8, loose), (4, loose)):
             planes = torch.zeros((2 * words,), dtype=torch.int64, device=DEV)
             scales = torch.empty((2, x.shape[0]), dtype=torch.float32, device=DEV)
             with hip.debug_switches(fused_mode=mode), hip.solver_trace(x.shape[0], DEV) as trace:
-                hip.act_quant(x.to(DEV), geom, hip.SCHEME_LST if ternary else hip.SCHEME_LS2, 2, 3, -1.0, planes, scales)
+                hip.act_quant(x.to(DEV), geom, hip.SCHEME_LST if ternary else hip.SCHEME_LS2, 2, 3, alpha, planes, scales)
                 torch.cuda.synchronize()
                 pos = trace.cpu().numpy().copy()
-            _check_positions(tag, rows, ternary, skip, scales[0].cpu().numpy(), pos, g, f'act_quant mode {mode}')
+            _check_positions(tag, rows, ternary, skip, scales[0].cpu().numpy(), pos, g, f'act_quant mode {mode} alpha {alpha}')
 
 
 def test_trace_is_off_by_default_and_after_the_block():
