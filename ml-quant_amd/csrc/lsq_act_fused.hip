@@ -1066,19 +1066,34 @@ static __device__ __forceinline__ bool win_plan(FusedLds* lds, unsigned n, unsig
   //  conflict; lane L starts at bin (L >> 1) & 15 of its group and wraps around -- 32 lanes, 32 different bank pairs.  The
   //  order of the fp64 additions inside a group is then the lane's own, fixed, order: the terms are exact, the sum is
   //  the same number on every run)
-  unsigned gc = 0, first = kNoKey;
-  double gs = 0.0;
+  // (the 16 bins of a group share one binade -- groups are aligned and a binade is a multiple of 16 bins --, so the group's sum
+  //  is ONE integer: mant0 * sum(c) + (sum(c * u) << sh) + sum(low bits), converted and scaled once: the same number as the
+  //  sum of the sixteen exact bin sums, at a third of the instructions)
+  unsigned gc = 0, first = kNoKey, cu = 0;
+  unsigned long long lowsum = 0ull;
 #pragma unroll 4
   for (unsigned uu = 0; uu < BPL; ++uu) {
     const unsigned u = (uu + ((unsigned)tid >> 1)) & (BPL - 1u);
     const unsigned b = (unsigned)tid * BPL + u;
     const unsigned long long h = hist[b];
     const unsigned c = (unsigned)(h >> 42);
-    if (c) {
-      gs += bin_sum_exact(k0 + (b << sh), c, h & kLowMask);
-      gc += c;
-      first = min(first, b);
+    gc += c;
+    cu += c * u;
+    lowsum += h & kLowMask;
+    first = c ? min(first, b) : first;
+  }
+  double gs = 0.0;
+  if (gc) {
+    const unsigned hk = k0 + (((unsigned)tid * BPL) << sh);   // lowest key of the group
+    const int e = (int)(hk >> 23);
+    long long mant = (long long)(hk & 0x7FFFFFu);
+    int sc = -149;
+    if (e > 0) {
+      mant += 1ll << 23;
+      sc = e - 150;
     }
+    const long long integer = (long long)gc * mant + ((long long)cu << sh) + (long long)lowsum;     // < 2^47: exact in fp64
+    gs = (double)integer * __longlong_as_double((long long)(sc + 1023) << 52);
   }
   unsigned lc = 0;
   double ls = 0.0;
@@ -1346,35 +1361,43 @@ static __device__ __forceinline__ void win_sweep(FusedLds* lds, unsigned n, unsi
 #endif
 }
 
-// block argmin (first minimum in sorted order, optimal.py:151) -> lds->v1
-static __device__ __forceinline__ void block_argmin(FusedLds* lds, Best best) {
+// block argmin (first minimum in sorted order, optimal.py:151) -> lds->v1.  Inside a wave the minimum travels upwards on
+// DPP moves (row shifts, then the two row broadcasts: lane 63 ends up with the wave's best; a lane without a source compares
+// with itself) -- the butterfly of __shfl_xor is six times four LDS-crossbar round trips --, and every lane then takes the
+// minimum over the eight waves' entries itself (broadcast reads), so no second barrier is needed for the result.
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ Best dpp_best(const Best& b) {
+  Best o;
+  const unsigned long long c = (unsigned long long)__double_as_longlong(b.cost);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)c, (int)(unsigned)c, CTRL, ROW_MASK, 0xF, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(c >> 32), (int)(unsigned)(c >> 32), CTRL, ROW_MASK, 0xF, false);
+  o.cost = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  o.order = (unsigned)__builtin_amdgcn_update_dpp((int)b.order, (int)b.order, CTRL, ROW_MASK, 0xF, false);
+  o.value = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(b.value), __float_as_int(b.value), CTRL, ROW_MASK, 0xF, false));
+  return o;
+}
+static __device__ __forceinline__ float block_argmin(FusedLds* lds, Best best) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    Best o;
-    o.cost = __shfl_xor(best.cost, d);
-    o.order = __shfl_xor(best.order, d);
-    o.value = __shfl_xor(best.value, d);
-    if (better(o, best)) best = o;
-  }
-  if (lane == 0) lds->wbest[wid] = best;
+  Best o;
+  o = dpp_best<0x111, 0xF>(best); if (better(o, best)) best = o;     // row_shr:1
+  o = dpp_best<0x112, 0xF>(best); if (better(o, best)) best = o;     // row_shr:2
+  o = dpp_best<0x114, 0xF>(best); if (better(o, best)) best = o;     // row_shr:4
+  o = dpp_best<0x118, 0xF>(best); if (better(o, best)) best = o;     // row_shr:8
+  o = dpp_best<0x142, 0xA>(best); if (better(o, best)) best = o;     // row_bcast:15 into rows 1 and 3
+  o = dpp_best<0x143, 0xC>(best); if (better(o, best)) best = o;     // row_bcast:31 into rows 2 and 3
+  if (lane == 63) lds->wbest[wid] = best;
   lds_barrier();
-  if (wid == 0) {
-    Best r = lds->wbest[lane & (kWaves - 1)];
+  Best r = lds->wbest[0];
 #pragma unroll
-    for (int d = kWaves / 2; d > 0; d >>= 1) {
-      Best o;
-      o.cost = __shfl_xor(r.cost, d);
-      o.order = __shfl_xor(r.order, d);
-      o.value = __shfl_xor(r.value, d);
-      if (better(o, r)) r = o;
-    }
-    if (lane == 0) {
-      lds->v1 = r.value;   // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
-      lds->best_order = r.order;
-    }
+  for (int q = 1; q < kWaves; ++q) {
+    const Best c = lds->wbest[q];
+    if (better(c, r)) r = c;
   }
-  lds_barrier();
+  if (tid == 0) {
+    lds->v1 = r.value;     // 0.0 when no candidate exists (zero padding wins, optimal.py:148-153)
+    lds->best_order = r.order;
+  }
+  return r.value;
 }
 
 // The ternary scheme's extra candidate (optimal.py:86-118: min > mean / 2 adds mean / 2), then the block argmin -> v1.
@@ -1390,8 +1413,7 @@ static __device__ __forceinline__ float finish_best(FusedLds* lds, unsigned n, u
       if (better(c, best)) best = c;
     }
   }
-  block_argmin(lds, best);
-  return lds->v1;
+  return block_argmin(lds, best);
 }
 
 // Everything between the level-1 histogram and v1.  `each_key` as in refine_resident.

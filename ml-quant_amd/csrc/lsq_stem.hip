@@ -36,6 +36,14 @@
 
 #include "lsq_common.h"
 
+// The waves of a workgroup talk to each other through LDS only (patch, horizontal maxima, carry); __syncthreads() would also
+// drain the vector-memory counter -- the output stores of the chunk before and the prefetched patch of the next one -- at
+// every one of the three barriers per chunk.
+#ifndef LSQ_STEM_SYNCTHREADS
+#define STEM_BARRIER() lds_barrier()
+#else
+#define STEM_BARRIER() __syncthreads()
+#endif
 namespace lsq {
 namespace {
 
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 #endif
   SCLK();
   for (int ck = 0; ck < chunks; ++ck) {
-    __syncthreads();                      // the previous chunk's patch and hbuf are done with
+    STEM_BARRIER();                       // the previous chunk's patch and hbuf are done with
     SCLK();
     if constexpr (kPrefetch) {
       convert(0, pre);
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
         convert(h0, t);
       }
     }
-    __syncthreads();
+    STEM_BARRIER();
     SCLK();
     if constexpr (kPrefetch) {
       if (ck + 1 < chunks) request(ck + 1, 0, pre);
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       }
     }
     SCLK();
-    __syncthreads();
+    STEM_BARRIER();
     SCLK();
     // ---- vertical 3-max (stride 2), bias, ReLU, store: 64 channels x 4 pooled rows x 16 pooled columns
     if ((a.Wp & 3) == 0) {

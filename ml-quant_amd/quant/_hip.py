@@ -7,6 +7,7 @@ eager fallback here: if the library is missing, or a call fails, an exception is
 
 import contextlib
 import ctypes
+import warnings
 import os
 import threading
 from typing import Optional, Sequence
@@ -23,6 +24,8 @@ SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
 MAX_SOLVER_KEYS = 1 << 22    # lsq_act_quant LS-2 / LS-T: sub-sampled keys per row
+XNOR_MFMA_MAX_OUTPUTS = 1 << 30      # lsq_xnor_conv2d: at this many outputs the popcount kernel serves the call (same bits)
+_xnor_limit_warned = set()
 
 
 class ConvGeom(ctypes.Structure):
@@ -375,6 +378,13 @@ def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: tor
     m = geom.C * geom.H * geom.W
     macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
     nres = (res_pre is not None) + (res_post is not None)
+    if y.numel() >= XNOR_MFMA_MAX_OUTPUTS and (geom.KH, geom.KW, geom.groups, geom.dil_h, geom.dil_w) == (3, 3, 1, 1, 1) \
+            and geom.C in (64, 128, 256, 512) and geom.O % 32 == 0 and 'outputs' not in _xnor_limit_warned:
+        # (csrc/lsq_xnor_mfma.hip indexes its output with 32 bits: a call this large is served by the popcount kernel -- same
+        #  bits, about half the speed.  Said once, not silently.)
+        _xnor_limit_warned.add('outputs')
+        warnings.warn(f'lsq_xnor_conv2d: {y.numel()} outputs (2^30 or more): this call runs on the popcount kernel instead of the '
+                      'int8 matrix-core kernel (same result, about half the speed); split the batch to stay below 2^30 outputs')
     # algorithmic bytes: planes read + fp32 output written + every residual operand of the fused epilogue read
     with _on(y), (_Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
                          geom.N * kx * m // 8 + 4 * y.numel()) if _timing is not None else _UNTIMED):

@@ -13,8 +13,11 @@ Where this (and the HIP solver, which computes the same thing) intentionally dif
     on fp32 rounding of its own norm / mean reductions.  Either answer has the same least-squares cost.
   * the ternary extra candidate (half the row mean, optimal.py:147-152) is the fp64 mean rounded to fp32, up to one
     ulp from the reference's fp32 ``matrix.mean() / 2``;
-  * a row with no candidate returns 0 where the reference raises (cannot happen for rows of three or more elements
-    that are not all equal).
+  * a row with no candidate returns 0.  The reference raises only when NO row of the batch has one (``argmin`` over
+    an empty dimension, optimal.py:147-151: an ``IndexError``; a row without candidates next to one with gets the zero
+    of the padding) -- in practice rows of fewer than three elements.  ``STRICT_NO_CANDIDATE = True`` makes
+    ``opt_v1`` raise the same ``IndexError`` in that case (on the GPU it reads the solver's per-row status back: one
+    synchronisation per call, which is why it is not the default); the fused eval path of ``QuantConv2d`` never raises.
 On continuous data the results match the reference's bit for bit in most rows and within 1e-3 relative in the
 rest (near-tied candidates, see DESIGN.md section 7); tests/test_oracle_golden.py::test_exact_solver_vs_reference.
 """
@@ -23,6 +26,8 @@ from typing import Tuple
 
 import torch
 
+#: True: ``opt_v1`` raises ``IndexError`` like the reference when no row of the batch has a candidate (see above)
+STRICT_NO_CANDIDATE = False
 
 
 def _prefix(matrix: torch.Tensor):
@@ -111,6 +116,21 @@ def opt_v1(matrix: torch.Tensor, ternary: bool, skip: int = 1) -> torch.Tensor:
     with torch.no_grad():
         if matrix.is_cuda and matrix.dtype == torch.float32:     # (other dtypes: the torch formulation below)
             from quant import _hip
-            v12, _ = _hip.solve_rows(matrix, skip, ternary)
+            v12, status = _hip.solve_rows(matrix, skip, ternary)
+            if STRICT_NO_CANDIDATE and int(status.sum()) == 0:
+                raise IndexError('argmin(): Expected reduction dim 2 to have non-zero size.')     # (optimal.py:151 of the reference)
             return v12[0].view(-1, 1)
-        return _opt_v1_torch(matrix[..., ::skip].abs(), ternary)
+        a = matrix[..., ::skip].abs()
+        if STRICT_NO_CANDIDATE and not _any_candidate(a, ternary):
+            raise IndexError('argmin(): Expected reduction dim 2 to have non-zero size.')
+        return _opt_v1_torch(a, ternary)
+
+
+def _any_candidate(a: torch.Tensor, ternary: bool) -> bool:
+    """Does any row have a candidate (a masked inner position, or the ternary scheme's extra one)?"""
+    n = a.shape[1]
+    if n >= 3 and bool(compute_mask(a, ternary)[0].any()):
+        return True
+    if ternary and n > 0:
+        return bool((a.min(dim=1).values.to(torch.float64) > 0.5 * a.to(torch.float64).mean(dim=1)).any())
+    return False

@@ -161,6 +161,69 @@ def net_cases():
     return per
 
 
+def fp_cases():
+    """The schemes WITHOUT a search on fp activations (BASELINE configs 0 and 3): nothing to tie-break; what the GPU's
+    operand rounding (bf16 hi + lo split of the activations, oracle.ref_port.split_operands) moves, plus the network's
+    own sensitivity to arithmetic noise.  limit = 1.05 * split + 2 * sensitivity (tests: test_config0_lenet_and_fp_act_resnet_on_gpu)."""
+    from quant.models.lenet import QLeNet5
+    from quant.models.resnet import QResNet
+    g7, g6 = load('f7_lenet'), load('f6_models')
+    out = {}
+    arch = json.loads(bytes(g7['mnist_ls1w_fpa_arch'].numpy()).decode())
+    model = QLeNet5(loss_fn=None, **arch)
+    detgen.fill_module(model, seed=3)
+    with torch.no_grad():
+        model.conv2.w_approximate.v1.copy_(P.weight_scales(model.conv2.weight, 'ls-1')[0])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    x = detgen.normal('mnist_ls1w_fpa.x', (64, 1, 28, 28))
+    y = RM.lenet_forward(sd, arch, x)
+    assert rel_err(y, g7['mnist_ls1w_fpa_logp']) < 1e-6                    # (the functional LeNet is the reference's; bit-equal at its thread count)
+    with P.split_operands():
+        ys = RM.lenet_forward(sd, arch, x)
+    out['fp_lenet_logp'] = {'split': rel_err(ys, y), 'sensitivity': max(rel_err(RM.lenet_forward(sd, arch, perturbed(x, s)), y) for s in range(3))}
+    tag = 'imagenet_ls1w_fpa'
+    arch = json.loads(bytes(g6[tag + '_arch'].numpy()).decode())
+    model = QResNet(loss_fn=None, **arch)
+    sd = filled_state_dict(model, 1)
+    x = detgen.normal(tag + '.x', (2, 3, 64, 64))
+    y = RM.resnet_forward(sd, arch, x)
+    assert rel_err(y, g6[tag + '_logits']) < 1e-6
+    with P.split_operands():
+        ys = RM.resnet_forward(sd, arch, x)
+    out['fp_resnet_logits'] = {'split': rel_err(ys, y), 'sensitivity': max(rel_err(RM.resnet_forward(sd, arch, perturbed(x, s)), y) for s in range(3))}
+    for v in out.values():
+        v['limit'] = 1.05 * v['split'] + 2.0 * v['sensitivity']
+        v['formula'] = '1.05 * split + 2 * sensitivity'
+    return out
+
+
+CHAINED = {'chained_cifar_b100': ('cifar', 100, 1), 'chained_cifar_b7': ('cifar', 7, 1), 'chained_imagenet_ls1_b6': ('imagenet_ls1', 6, 2)}
+
+
+def chained_cases(only=None):
+    """The networks of test_chained_one_bit_layers_equal_the_unchained_network (bench.py's models, ls-1 activations: no search,
+    integer convolutions): against the oracle's logits of the same model the GPU differs by the fp32 order of operations of the
+    stem (MIOpen / lsq_stem_conv_pool), the folded batch norms and the scale sums only: north_star's 1e-4 for that, plus
+    2 * sensitivity of the first four samples (the ones the test compares) for what the network does with such noise.
+    Observed on the MI355X: 1e-6 (CIFAR, MIOpen 3x3 stem), 4.5e-7 (ImageNet ls-1)."""
+    import bench
+    out = {}
+    for key, (which, batch, seed) in CHAINED.items():
+        if only is not None and key not in only:
+            continue
+        arch = bench.cifar_arch() if which == 'cifar' else bench.imagenet_arch('ls-1', 2)
+        model = bench.build_model(arch, torch.device('cpu'))
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        size = 32 if which == 'cifar' else 224
+        x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(seed))[:4]
+        y = RM.resnet_forward(sd, arch, x)
+        sens = max(rel_err(RM.resnet_forward(sd, arch, perturbed(x, s)), y) for s in range(3))
+        out[key] = {'sensitivity': sens, 'limit': TOL + 2.0 * sens,
+                    'formula': '1e-4 (north_star\'s bound on a layer: the fp32 stem and scale sums are MIOpen\'s / the kernels\' order of operations, '
+                               'not the CPU\'s) + 2 * sensitivity (no search, exact integer convolutions: nothing else to move)'}
+    return out
+
+
 def main():
     torch.set_num_threads(4)
     out = conv_layers()
@@ -182,6 +245,8 @@ def main():
     out['fused_cos_modular'] = {'limit': max(2.0 * nets[t]['sensitivity_cos'] for t in fused),
                                 'formula': 'GPU against GPU (same solver on both sides): max over configs of 2 * sensitivity'}
     out['block_cos_modular'] = {'limit': 2.0 * blk['block_cos']['sensitivity'], 'formula': 'GPU against GPU: 2 * sensitivity of the block'}
+    out.update(fp_cases())
+    out.update(chained_cases())
     for k, v in out.items():
         if 'cos' in k:
             v['limit'] = max(v['limit'], 1e-9)
@@ -193,7 +258,7 @@ def main():
     with open(path, 'w') as f:
         json.dump(doc, f, indent=1, sort_keys=True)
     for k, v in sorted(out.items()):
-        print(f"{k:20s} limit {v['limit']:.3e}  " + '  '.join(f'{a} {b:.3e}' for a, b in v.items() if a in ('tiebreak', 'sensitivity')))
+        print(f"{k:24s} limit {v['limit']:.3e}  " + '  '.join(f'{a} {b:.3e}' for a, b in v.items() if a in ('tiebreak', 'sensitivity', 'split')))
     for t, v in nets.items():
         print(t, {a: float('%.3e' % b) for a, b in v.items()})
 

@@ -560,12 +560,16 @@ def test_config0_lenet_and_fp_act_resnet_on_gpu(golden):
     model.eval().to(DEV)
     with torch.no_grad():
         y = model(detgen.normal('mnist_ls1w_fpa.x', (64, 1, 28, 28)).to(DEV)).cpu()
-    assert torch.allclose(y, g7['mnist_ls1w_fpa_logp'], atol=2e-4, rtol=0)
+    # (limits derived on the CPU, tests/golden/make_free_limits.py fp_cases: what the kernel's bf16 hi + lo operand split alone
+    #  moves the oracle's output by, x 1.05, plus twice the network's sensitivity to ulp-sized input noise)
+    e0 = observe('fp_lenet_logp', rel_err(y, g7['mnist_ls1w_fpa_logp']))
+    assert e0 <= FREE_LIMIT['fp_lenet_logp'], (e0, FREE_LIMIT['fp_lenet_logp'])
     tag = 'imagenet_ls1w_fpa'
     model = _build_model(g6.json(tag + '_arch'), seed=1).to(DEV)
     with torch.no_grad():
         y = model(detgen.normal(tag + '.x', (2, 3, 64, 64)).to(DEV)).cpu()
-    assert rel_err(y, g6[tag + '_logits']) <= 1e-3, rel_err(y, g6[tag + '_logits'])
+    e3 = observe('fp_resnet_logits', rel_err(y, g6[tag + '_logits']))
+    assert e3 <= FREE_LIMIT['fp_resnet_logits'], (e3, FREE_LIMIT['fp_resnet_logits'])
 
 
 # ------------------------------------------------------------------------------------------------

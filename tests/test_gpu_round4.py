@@ -312,7 +312,13 @@ def test_chained_one_bit_layers_equal_the_unchained_network(which, batch):
     arch = bench.cifar_arch() if which == 'cifar' else bench.imagenet_arch('ls-1', 2)
     ref = ref_models.resnet_forward(sd, arch, x.cpu()[:4])
     got = out[True].cpu()[:4]
-    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # (limit derived on the CPU, tests/golden/make_free_limits.py chained_cases: no search and exact integer convolutions in
+    #  these networks -- north_star's 1e-4 for the fp32 order of operations of stem and scales, plus twice the oracle network's
+    #  own sensitivity to ulp-sized input noise on these four samples)
+    import test_gpu_parity as TP
+    key = f'chained_{which}_b{batch}'
+    err = TP.observe(key, float((got - ref).abs().max()) / float(ref.abs().max()))
+    assert err <= TP.FREE_LIMIT[key], (key, err, TP.FREE_LIMIT[key])
 
 
 def test_lone_row_split_sweep_replayed_in_a_graph():

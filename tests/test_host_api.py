@@ -406,3 +406,21 @@ def test_fused_forward_cpu_composition_with_prelu_and_identity():
     assert R._act_args(torch.nn.ReLU()) == {'relu': True} and R._act_args(torch.nn.Identity()) == {}
     p = torch.nn.PReLU()
     assert R._act_args(p)['prelu'] is p.weight and R._act_args(torch.nn.Sigmoid()) is None
+
+
+def test_opt_v1_strict_flag_on_the_host():
+    """The reference's opt_v1 raises (argmin over an empty dimension, optimal.py:147-151) when NO row of the batch has a
+    candidate; the product returns zeros by default and raises the same IndexError under STRICT_NO_CANDIDATE."""
+    from quant.binary import optimal
+    no_candidate = torch.tensor([[1.0, 2.0], [0.5, -0.25]])              # two elements per row: no inner position
+    some = torch.tensor([[0.1, 0.2, 0.9, 1.0, 1.1], [1.0, 1.0, 1.0, 1.0, 1.0]])
+    assert float(optimal.opt_v1(no_candidate, False).abs().sum()) == 0.0
+    optimal.STRICT_NO_CANDIDATE = True
+    try:
+        with pytest.raises(IndexError):
+            optimal.opt_v1(no_candidate, False)
+        assert torch.equal(optimal.opt_v1(torch.ones(3, 7), False), torch.ones(3, 1))   # all-equal rows DO have candidates (m = v)
+        assert optimal.opt_v1(some, False).shape == (2, 1)                   # one row with a candidate is enough
+        assert optimal.opt_v1(torch.ones(3, 7), True).shape == (3, 1)        # ternary: the extra candidate mean / 2 exists
+    finally:
+        optimal.STRICT_NO_CANDIDATE = False
