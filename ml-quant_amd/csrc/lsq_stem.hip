@@ -29,10 +29,15 @@
 // One 256-thread workgroup = one image x four pooled rows (nine conv rows: one halo row recomputed), walked in
 // chunks of 32 conv columns.  Per chunk: stage the 23 x 72 input patch of the three channels as 16-bit term
 // planes in LDS; wave w owns out-channel tile w / 2 and conv rows w % 2, w % 2 + 2, ...: 66 (33) MFMAs per
-// row on two accumulators (leading products, cross terms); the three row-neighbours of each pixel are combined with two
-// cross-lane moves (horizontal 3-max, stride 2; the column left of the chunk comes from an LDS carry written by
-// the previous chunk) and the 16 x 9 x 64 partial maxima go to LDS; then all lanes take the vertical 3-max,
-// add the bias, apply the ReLU (both commute with the max) and store 64-byte segments of the NCHW output.
+// row on two accumulators (leading products, cross terms) with the operands in the order (pixels, weights), i.e.
+// D[pixel][out-channel]: a lane holds ONE out-channel and four groups of four consecutive columns, so the horizontal
+// 3-max (stride 2) is lane-local except for the column in front of each group, which the other lane half holds (one
+// v_permlane32_swap per group; the column left of the chunk comes from an LDS carry the same wave wrote for the previous
+// chunk) -- round 5: a third of the VALU instructions of the lane-per-pixel layout of rounds 2-4, in a kernel that was
+// VALU-bound (6.8 VALU instructions per MFMA): 0.40 -> 0.37 ms in the network.  The 16 x 9 x 64 partial maxima go to
+// LDS; then all lanes take the vertical 3-max, add the bias, apply the ReLU (both commute with the max) and store
+// 64-byte segments of the NCHW output.  Every barrier is LDS-only (lds_barrier): the output stores and the prefetched
+// patch of the next chunk stay in flight across them.
 
 #include "lsq_common.h"
 
@@ -98,6 +103,7 @@ constexpr int kIR = 2 * kCR + 5;          // input rows per workgroup (23)
 constexpr int kIC = 72;                   // staged input columns per chunk: 2 * 32 + 5, padded to a multiple of 8
 constexpr int kSteps = 11;                // K = 176 = 11 x 16
 constexpr int kO = 64;
+constexpr int kHS = 20;                   // floats per (row, channel) of the horizontal maxima: 16 + 4 (16-byte aligned rows, 2-way banks)
 
 struct StemArgs {
   const float* x;      // [N][3][H][W]
@@ -111,7 +117,7 @@ struct StemArgs {
 template <int SPLIT>
 struct StemLds {
   unsigned xs[SPLIT][3 * kIR * kIC / 2];  // bf16 pairs of each split term, [c][row][col]
-  float hbuf[kCR][kO][16];                // horizontal 3-max (stride 2) of every conv row of the chunk
+  float hbuf[kCR][kO][kHS];               // horizontal 3-max (stride 2) of every conv row of the chunk (rows padded: bank spread)
   float carry[kCR][2][2][16];             // last conv column of the previous chunk: [row][out-channel tile][lane half][reg]
 };
 
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       f32x16 acc0 = {}, acc1 = {};        // leading products; all cross terms (<= 2^-8 of them: summed apart)
       // B fragments: the reads of step s + 1 are issued before the MFMAs of step s (two register sets); the
       // scheduling barriers keep it at two -- left alone, the scheduler hoists several steps' reads and spills
-      Frag bf[2][SPLIT];
+      constexpr int kDepth = 2;           // register sets of pixel fragments (three and four measured the same: round 5)
+      Frag bf[kDepth][SPLIT];
       auto load_b = [&](int s, int which) {
         const int rr2 = min(2 * s + g, 20);
         const int kh = rr2 / 3, c = rr2 - kh * 3;
@@ -245,61 +252,65 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
 #pragma unroll
           for (int j = 0; j < 4; ++j) bf[which][i].u[j] = lds.xs[i][off + j];
       };
-      load_b(0, 0);
+#pragma unroll
+      for (int s = 0; s < kDepth - 1; ++s) load_b(s, s % kDepth);
 #pragma unroll
       for (int s = 0; s < kSteps; ++s) {
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < kSteps) load_b(s + 1, (s + 1) & 1);
+        if (s + kDepth - 1 < kSteps) load_b(s + kDepth - 1, (s + kDepth - 1) % kDepth);
         __builtin_amdgcn_sched_barrier(0);
-        const Frag* b = bf[s & 1];
+        const Frag* b = bf[s % kDepth];
         // (the leading product BETWEEN the two cross terms: two MFMAs on the same accumulator back to back wait for each other)
         if constexpr (HALF) {
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][s].h, b[0].h, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][s].h, b[0].h, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][s].h, b[1].h, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0].h, af[1][s].h, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[0].h, af[0][s].h, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[1].h, af[0][s].h, acc1, 0, 0, 0);
         } else {
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[0].v, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[0].v, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[1].v, acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0].v, af[1][s].v, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0].v, af[0][s].v, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1].v, af[0][s].v, acc1, 0, 0, 0);
           if constexpr (SPLIT == 3) {
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][s].v, b[2].v, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][s].v, b[0].v, acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][s].v, b[1].v, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[2].v, af[0][s].v, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0].v, af[2][s].v, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[1].v, af[1][s].v, acc1, 0, 0, 0);
           }
         }
       }
-      // lane: pixel x = 32 ck + xl_, out-channels mt * 32 + (reg & 3) + 8 (reg >> 2) + 4 g.  Horizontal 3-max with
-      // stride 2: the neighbours come from wave-wide one-lane shifts (DPP, no LDS round trip); lanes 0 / 32 take
-      // their left neighbour -- the last column of the previous chunk -- from the carry, lanes 31 / 63 leave theirs.
+      // The MFMA operands are (pixels, weights): D[pixel][out-channel], so a lane holds ONE out-channel (mt * 32 + lane % 32)
+      // and sixteen pixels x = (reg & 3) + 8 (reg >> 2) + 4 g of the chunk -- groups of four consecutive columns.  The
+      // horizontal 3-max with stride 2 is then mostly lane-local: of a group [4k, 4k + 3] the centre 4k + 2 needs the
+      // group's own three last columns, the centre 4k the column in front of the group, which the OTHER lane half holds
+      // (groups alternate between the halves): one v_permlane32_swap per group.  44 VALU instructions per row and tile
+      // where the lane-per-pixel layout (two one-lane shifts and two maxima per accumulator register, half of the lanes
+      // idle at the store) took 130 -- the stem was VALU-bound (6.8 VALU instructions per MFMA, round 4's counters).
       const bool full = 32 * ck + 32 <= a.Wc;                  // (uniform) no column of the chunk is past the row's end
-      const bool x_ok = 32 * ck + xl_ < a.Wc;
       float v[16];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) v[reg] = HALF ? fmaf(acc1[reg], 1.f / kLoScale, acc0[reg]) : acc1[reg] + acc0[reg];
       if (!full) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) v[reg] = x_ok ? v[reg] : ninf;
+        for (int reg = 0; reg < 16; ++reg) v[reg] = 32 * ck + (reg & 3) + 8 * (reg >> 2) + 4 * g < a.Wc ? v[reg] : ninf;
       }
-      float4 cv[4];                                            // lanes 0 / 32: column 31 of the previous chunk
-      if (xl_ == 0) {
+      float* const cw = &lds.carry[q][mt][0][0];               // 32 floats per (row, tile): column 31 of the previous chunk
+      float prev0 = 0.f;
+      if (g == 0) prev0 = cw[xl_];
+      float lo_from_hi[4], hi_from_lo[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cv[k] = *reinterpret_cast<const float4*>(&lds.carry[q][mt][g][4 * k]);
+      for (int G = 0; G < 4; ++G) {
+        const unsigned t = __float_as_uint(v[4 * G + 3]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+        hi_from_lo[G] = __uint_as_float(sw[0]);                // upper lanes: the lower half's column 8 G + 3
+        lo_from_hi[G] = __uint_as_float(sw[1]);                // lower lanes: the upper half's column 8 G + 7
       }
+      const int ch = mt * 32 + xl_;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int ch = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * g;
-        const int vi = __float_as_int(v[reg]);
-        float left = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x138, 0xF, 0xF, false));    // wave_shr:1
-        const float right = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x130, 0xF, 0xF, false));   // wave_shl:1
-        if (xl_ == 0) left = reinterpret_cast<const float*>(&cv[reg >> 2])[reg & 3];
-        // (a centre is an even column: lane 31 / 63, whose right neighbour belongs to the next chunk, stores nothing)
-        if ((xl_ & 1) == 0) lds.hbuf[q][ch][xl_ >> 1] = fmaxf(fmaxf(left, v[reg]), right);
+      for (int G = 0; G < 4; ++G) {
+        const float before = g ? hi_from_lo[G] : (G ? lo_from_hi[G ? G - 1 : 0] : prev0);     // column 8 G + 4 g - 1
+        const float ca = fmaxf(fmaxf(before, v[4 * G]), v[4 * G + 1]);                           // pooled column 4 G + 2 g
+        const float cb = fmaxf(fmaxf(v[4 * G + 1], v[4 * G + 2]), v[4 * G + 3]);                 // pooled column 4 G + 2 g + 1
+        *reinterpret_cast<float2*>(&lds.hbuf[q][ch][4 * G + 2 * g]) = make_float2(ca, cb);
       }
-      if (xl_ == 31) {                                         // (lanes 0 / 32 have read theirs above)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          *reinterpret_cast<float4*>(&lds.carry[q][mt][g][4 * k]) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-      }
+      if (g == 1) cw[xl_] = v[15];                             // column 31, for the next chunk (this wave's own: no barrier)
     }
     SCLK();
     STEM_BARRIER();
