@@ -118,7 +118,8 @@ template <int SPLIT>
 struct StemLds {
   unsigned xs[SPLIT][3 * kIR * kIC / 2];  // bf16 pairs of each split term, [c][row][col]
   float hbuf[kCR][kO][kHS];               // horizontal 3-max (stride 2) of every conv row of the chunk (rows padded: bank spread)
-  float carry[kCR][2][2][16];             // last conv column of the previous chunk: [row][out-channel tile][lane half][reg]
+  float carry[kCR][2][2][16];             // last conv column of the previous chunk: [row][out-channel tile][32 out-channels]
+  float bias[kO];
 };
 
 template <int SPLIT, bool HALF>
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
     }
   }
   for (int i = tid; i < kCR * kO; i += 256) (&lds.carry[0][0][0][0])[i] = ninf;
+  if (tid < kO) lds.bias[tid] = a.bias[tid];
 
   const float* __restrict__ xn = a.x + (long long)n * 3 * a.H * a.W;
   const int chunks = (a.Wc + 31) / 32;
@@ -317,23 +319,32 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
     SCLK();
     // ---- vertical 3-max (stride 2), bias, ReLU, store: 64 channels x 4 pooled rows x 16 pooled columns
     if ((a.Wp & 3) == 0) {
-      // four columns per lane: 16-byte LDS reads and global stores (a group of four is inside the row or outside it)
-      for (int e = tid; e < kO * kPH * 4; e += 256) {
-        const int j4 = e & 3, p = (e >> 2) & (kPH - 1), ch = e >> 4;
-        const int pr = pr0 + p, pc = 16 * ck + 4 * j4;
-        if (pr < a.Hp && pc < a.Wp) {
-          float4 m = make_float4(ninf, ninf, ninf, ninf);
+      // four columns per lane: 16-byte LDS reads and global stores (a group of four is inside the row or outside it).  A
+      // thread keeps its pooled row p and its column group j4 over the four passes and moves 16 channels on: every LDS
+      // read of the four passes (three rows of maxima and the bias, staged in LDS) goes out before the first is used --
+      // written as a loop with the bias read from memory inside, each pass paid a round trip of its own (5 - 7 k of the
+      // 22 k cycles of a chunk, round 5's stamps).
+      const int j4 = tid & 3, p = (tid >> 2) & (kPH - 1), ch0 = tid >> 4;
+      const int pr = pr0 + p, pc = 16 * ck + 4 * j4;
+      if (pr < a.Hp && pc < a.Wp) {
+        float4 h[4][3];
+        float b[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) {
             const int q = 2 * p + d, cr = cr0 + q;
-            if (cr >= 0 && cr < a.Hc) {
-              const float4 h = *reinterpret_cast<const float4*>(&lds.hbuf[q][ch][4 * j4]);
-              m.x = fmaxf(m.x, h.x); m.y = fmaxf(m.y, h.y); m.z = fmaxf(m.z, h.z); m.w = fmaxf(m.w, h.w);
-            }
+            h[it][d] = make_float4(ninf, ninf, ninf, ninf);
+            if (cr >= 0 && cr < a.Hc) h[it][d] = *reinterpret_cast<const float4*>(&lds.hbuf[q][ch0 + 16 * it][4 * j4]);
           }
-          const float b = a.bias[ch];
-          *reinterpret_cast<float4*>(a.y + (((long long)n * kO + ch) * a.Hp + pr) * a.Wp + pc) =
-              make_float4(fmaxf(m.x + b, 0.f), fmaxf(m.y + b, 0.f), fmaxf(m.z + b, 0.f), fmaxf(m.w + b, 0.f));
+          b[it] = lds.bias[ch0 + 16 * it];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const float4 m = make_float4(fmaxf(fmaxf(h[it][0].x, h[it][1].x), h[it][2].x), fmaxf(fmaxf(h[it][0].y, h[it][1].y), h[it][2].y),
+                                       fmaxf(fmaxf(h[it][0].z, h[it][1].z), h[it][2].z), fmaxf(fmaxf(h[it][0].w, h[it][1].w), h[it][2].w));
+          *reinterpret_cast<float4*>(a.y + (((long long)n * kO + ch0 + 16 * it) * a.Hp + pr) * a.Wp + pc) =
+              make_float4(fmaxf(m.x + b[it], 0.f), fmaxf(m.y + b[it], 0.f), fmaxf(m.z + b[it], 0.f), fmaxf(m.w + b[it], 0.f));
         }
       }
     } else {
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
             const int q = 2 * p + d, cr = cr0 + q;
             if (cr >= 0 && cr < a.Hc) m = fmaxf(m, lds.hbuf[q][ch][j]);
           }
-          a.y[(((long long)n * kO + ch) * a.Hp + pr) * a.Wp + pc] = fmaxf(m + a.bias[ch], 0.f);
+          a.y[(((long long)n * kO + ch) * a.Hp + pr) * a.Wp + pc] = fmaxf(m + lds.bias[ch], 0.f);
         }
       }
     }

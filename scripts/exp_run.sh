@@ -1,3 +1,3 @@
-for r in 1 2; do for t in s2 sw; do echo "== $t"; LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/$t/liblsq_hip.so python scripts/stem_time.py 2>&1 | grep -v amdgpu | tail -3; done; done
-LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/sw/liblsq_hip.so python -m pytest tests/test_gpu_round3.py tests/test_gpu_parity.py -q -m gpu -k "stem" 2>&1 | tail -3
-for t in s2 sw; do echo "== bench $t"; LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/$t/liblsq_hip.so python bench.py --no-configs --cpu-sample 0 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['single_stream']['value'], d['roofline']['other_kernels_ms_per_step'])"; done
+for r in 1 2; do for t in sw sv; do echo "== $t"; LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/$t/liblsq_hip.so python scripts/stem_time.py 2>&1 | grep -v amdgpu | tail -1; done; done
+LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/sv/liblsq_hip.so python -m pytest tests/test_gpu_round3.py tests/test_gpu_parity.py -q -m gpu -k "stem" 2>&1 | tail -2
+LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/svc/liblsq_hip.so python scripts/stem_clocks.py 2>&1 | grep "split 22"
