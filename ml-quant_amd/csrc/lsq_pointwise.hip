@@ -17,6 +17,13 @@
 
 #include "lsq_common.h"
 
+// (the waves of a workgroup exchange the operand tiles through LDS only: __syncthreads() would also wait for the NEXT tile's
+//  global loads, which are issued precisely so that they are in flight during the MFMAs)
+#ifdef LSQ_PW_SYNCTHREADS
+#define PW_BARRIER() __syncthreads()
+#else
+#define PW_BARRIER() lds_barrier()
+#endif
 namespace lsq {
 namespace {
 
@@ -208,13 +215,13 @@ __global__ __launch_bounds__(256) void pointwise_all_kernel(PwArgs a) {
   load_w(0, 0);
   int buf = 0;
   for (int cc = 0; cc < nchunks; ++cc) {
-    __syncthreads();                       // the x fragments of the previous chunk have been read
+    PW_BARRIER();                          // the x fragments of the previous chunk have been read
     store_x();
     if (cc + 1 < nchunks) load_x(64 * (cc + 1));
 #pragma unroll
     for (int t = 0; t < NOT; ++t) {
       store_w(buf);                        // (the tile two steps back was read before the barrier of the step in between)
-      __syncthreads();
+      PW_BARRIER();
       if (t + 1 < NOT) load_w(t + 1, 64 * cc);
       else if (cc + 1 < nchunks) load_w(0, 64 * (cc + 1));
 #pragma unroll

@@ -26,10 +26,15 @@ from typing import List, Optional
 
 import torch
 import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
 
 
 def supported(conv, x: torch.Tensor) -> bool:
-    """Train-mode forward + backward on the kernels: fp32 4-d CUDA input, binary weights, plain geometry."""
+    """Train-mode forward + backward on the kernels: fp32 4-d CUDA input, binary weights, plain geometry -- and the library
+    built (without it a training run on a GPU host takes the torch formulation; the eval path, by contrast, raises)."""
+    from quant import _hip
+    if not _hip.available():
+        return False
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and conv.weight.dtype == torch.float32):
         return False
     if conv.w_quant == 'fp' or conv.padding_mode != 'zeros' or isinstance(conv.padding, str):
@@ -100,6 +105,7 @@ class _QuantConv2dStep(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable                       # (the straight-through kernels have no second derivative: say so instead of returning a wrong one)
     def backward(ctx, gy):
         from quant import _hip
         conv, geom, alpha = ctx.conv, ctx.geom, ctx.alpha

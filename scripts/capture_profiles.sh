@@ -12,12 +12,12 @@ python bench.py --act fp --no-configs --detail $o/${tag}_bench_n1_fpact_detail.j
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 \
   --steps 100 --cpu-sample 0 --no-configs > $o/${tag}_bench_torchrun_n1_ls2.json 2> $o/bench_torchrun.err
 rm -rf $o/prof_final
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_final -- python bench.py --steps 30 --warmup 5 --cpu-sample 0 --no-configs --streams 1 > $o/prof_final.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_final -- python bench.py --steps 30 --warmup 5 --min-seconds 0 --cpu-sample 0 --no-configs --streams 1 > $o/prof_final.log 2>&1
 f=$(ls -t $o/prof_final/*/*kernel_trace.csv | head -1)
 python scripts/trace_summary.py $f 10 > $o/${tag}_rocprofv3_per_step_summary.csv
 cp $(ls -t $o/prof_final/*/*kernel_stats.csv | head -1) $o/${tag}_rocprofv3_kernel_stats_incl_warmup.csv
 rm -rf $o/prof_fp
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --steps 30 --warmup 5 --cpu-sample 0 --no-configs --streams 1 > $o/prof_fp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_fp -- python bench.py --act fp --steps 30 --warmup 5 --min-seconds 0 --cpu-sample 0 --no-configs --streams 1 > $o/prof_fp.log 2>&1
 python scripts/trace_summary.py $(ls -t $o/prof_fp/*/*kernel_trace.csv | head -1) 10 > $o/${tag}_rocprofv3_per_step_summary_fpact.csv
 scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic.json > $o/pmc.log 2>&1
 scripts/pmc_traffic.sh $o/${tag}_pmc_hbm_traffic_fpact.json --act fp > $o/pmc_fp.log 2>&1
@@ -31,11 +31,20 @@ for s in "64 56 64 1 4" "64 56 128 2 1" "128 28 128 1 3" "128 28 256 2 1" "256 1
 done
 scripts/pmc_kernel.sh stem_conv_pool stem python scripts/stem_one.py > $o/pmc_stem.txt 2>&1
 python scripts/pmc_sq_table.py $o/${tag}_pmc_sq.json $specs lsq_stem_conv_pool:224x224:1:stem_conv_pool:$o/pmc_stem > $o/${tag}_pmc_sq.txt 2>&1
-for u in valu_rates launch_overhead; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o /tmp/$u 2> $o/$u.build.log && /tmp/$u > $o/${tag}_ubench_$u.txt 2>&1
+for u in valu_rates launch_overhead lds_atomics; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/$u.hip -o /tmp/$u 2> $o/$u.build.log && /tmp/$u > $o/${tag}_ubench_$u.txt 2>&1
 done
 python scripts/kbench.py > $o/${tag}_kbench.txt 2>&1
 python scripts/ls1_chain.py > $o/${tag}_ls1_chain.txt 2>&1
 python scripts/xnor_variants.py > $o/${tag}_xnor_variants.txt 2>&1
 python scripts/kbench.py --fold > $o/${tag}_kbench_bnfold.txt 2>&1
+# round 5: what runs under what when consecutive steps alternate between two HIP streams (the headline's issue order)
+rm -rf $o/prof_ov
+rocprofv3 --kernel-trace --output-format csv -d $o/prof_ov -- python bench.py --steps 30 --warmup 5 --min-seconds 0 --cpu-sample 0 --no-configs --no-roofline --streams 2 > $o/prof_ov.log 2>&1
+python scripts/overlap_trace.py $(ls -t $o/prof_ov/*/*kernel_trace.csv | head -1) 10 110 > $o/${tag}_two_stream_overlap.txt 2>&1
+rm -rf $o/prof_ov
+# what the free-running parity assertions observe on this box, next to their derived limits
+LSQ_RECORD_PARITY=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round4.py -q -m gpu > $o/parity_tests.log 2>&1
+cp $o/free_running_observed.json $o/${tag}_free_running_parity.json
+python scripts/sched_variants.py 40 > $o/${tag}_sched_variants.txt 2>&1
 head -3 $o/${tag}_rocprofv3_per_step_summary.csv; cut -c1-300 $o/${tag}_bench_n1_ls2.json; cut -c1-160 $o/${tag}_bench_n1_fpact.json

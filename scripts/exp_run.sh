@@ -1,3 +1,2 @@
-for r in 1 2; do for t in sw sv; do echo "== $t"; LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/$t/liblsq_hip.so python scripts/stem_time.py 2>&1 | grep -v amdgpu | tail -1; done; done
-LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/sv/liblsq_hip.so python -m pytest tests/test_gpu_round3.py tests/test_gpu_parity.py -q -m gpu -k "stem" 2>&1 | tail -2
-LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/svc/liblsq_hip.so python scripts/stem_clocks.py 2>&1 | grep "split 22"
+for r in 1 2; do echo "== base"; python scripts/pointwise_one.py 2>&1 | grep -v amdgpu | head -3 | cut -c1-90; echo "== pw1"; LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/pw1/liblsq_hip.so python scripts/pointwise_one.py 2>&1 | grep -v amdgpu | head -3 | cut -c1-90; done
+LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/pw1/liblsq_hip.so python -m pytest tests/ -q -m gpu -k "pointwise" 2>&1 | tail -2

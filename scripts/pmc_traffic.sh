@@ -9,7 +9,7 @@ out=$1; shift
 dir=gpurun_out/pmc_traffic
 rm -rf $dir; mkdir -p $dir
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $dir/$c -- python bench.py --steps 3 --warmup 2 --cpu-sample 0 --no-configs --no-roofline --streams 1 "$@" > $dir/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $dir/$c -- python bench.py --steps 3 --warmup 2 --min-seconds 0 --cpu-sample 0 --no-configs --no-roofline --streams 1 "$@" > $dir/$c.log 2>&1
 done
 python - "$dir" "$out" <<'PY'
 import collections, csv, glob, json, sys

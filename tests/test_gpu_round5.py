@@ -217,3 +217,68 @@ def test_xnor_convolution_across_the_matrix_core_kernels_output_limit():
         assert torch.equal(big[:8], small)
         below = conv(x[:4095])                                     # 2^30 - 2^18 outputs: the matrix-core kernel
         assert torch.equal(below[:8], small) and torch.equal(below[4000:4095], big[4000:4095])
+
+
+def test_sharded_step_on_two_streams_over_rccl_with_one_rank():
+    """What `evaluate` and bench.py do under ranks since round 5: the local forward of step i on one of two HIP streams, the
+    all-gather of its logits on the caller's stream behind the forward's event -- here with the one rank there is (RCCL
+    collective forced), five steps: every gathered batch equals the plain forward bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import bench
+    from quant.common.sharded_eval import all_gather_logits, local_forward
+    from quant.common.stream_pipeline import StreamPipeline
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        model = bench.build_model(bench.imagenet_arch(), torch.device(DEV))
+        xs = [torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(40 + i)).to(DEV) for i in range(5)]
+        with torch.no_grad():
+            want = [model(x).clone() for x in xs]
+            pipe = StreamPipeline(lambda shard: local_forward(model, shard), DEV, 2)
+            outs, window = [], []
+            for x in xs:
+                window.append(pipe.submit(x))
+                if len(window) >= pipe.depth:
+                    outs.append(all_gather_logits(window.pop(0).result(), total=8, always_collective=True).clone())
+            while window:
+                outs.append(all_gather_logits(window.pop(0).result(), total=8, always_collective=True).clone())
+            torch.cuda.synchronize()
+        assert len(outs) == 5 and all(torch.equal(o, w) for o, w in zip(outs, want))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_bench_line_under_torchrun_with_one_rank():
+    """The driver's launch line with one rank: rank 0's ONE JSON line carries the two-stream headline, the one-stream region,
+    both path kernels under fixed roofline keys, the all-gather and the parity object."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from quant.common.rank_launcher import free_port
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '3',
+           '--min-seconds', '0', '--cpu-sample', '0', '--no-configs']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['pipelined']['streams'] == 2 and out['value'] == out['pipelined']['value'] > 0
+    assert out['single_stream']['value'] > 0 and out['steps_timed'] == 10 and out['timed_seconds'] > 0
+    assert {'quantizer', 'xnor_conv'} <= set(out['roofline']) and out['roofline']['name'] in ('quantizer', 'xnor_conv')
+    for k in ('quantizer', 'xnor_conv'):
+        assert 0 < out['roofline'][k]['frac'] < 1
+    assert out['allgather']['backend'] == 'nccl' and out['allgather']['world_size_seen_by_backend'] == 1
+    assert len(lines[0]) < 8000                                   # (the driver keeps short lines whole)
