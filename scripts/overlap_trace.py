@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (round 5): what runs UNDER what when consecutive batches alternate between HIP streams.  Input: a rocprofv3
---kernel-trace CSV of `bench.py --streams 2`; the last `steps` forwards (the pipelined region) are analysed: how long the chip
+--kernel-trace CSV of `bench.py --streams 2` (two-stream region first, one-stream region after it); `steps` forwards of each: how long the chip
 had 0 / 1 / 2+ kernels in flight, per-kernel mean duration there against the same kernel in the single-stream region, and a
 timeline of one step.
     python scripts/overlap_trace.py <kernel_trace.csv> [steps] [timeline_rows]"""
@@ -19,8 +19,6 @@ def short(k):
 
 
 ends = [i for i, r in enumerate(rows) if 'MeanOps' in r['Kernel_Name']]          # avg-pool: once per forward
-queues = collections.Counter(r.get('Queue_Id', '?') for r in rows[ends[-steps - 1]:])
-print('queues in the analysed region:', dict(queues))
 
 
 def region(lo, hi):
@@ -44,12 +42,16 @@ def region(lo, hi):
     return t1 - t0, hist, per
 
 
-# single-stream region: forwards well before the end (the pipelined region is the last part of the run)
+# bench.py times the two-stream region FIRST (the headline) and the one-stream region after it: take `steps` forwards from
+# the middle of each, and tell them apart by the queues they ran on
 n_fw = len(ends)
-piped_lo, piped_hi = ends[-steps - 1] + 1, ends[-1] + 1
+first = (ends[n_fw // 4] + 1, ends[n_fw // 4 + steps] + 1)
+last = (ends[-steps - 1] + 1, ends[-1] + 1)
+nq = lambda r: len({row.get('Queue_Id', '?') for row in rows[r[0]:r[1]]})      # noqa: E731
+piped, single = (first, last) if nq(first) >= nq(last) else (last, first)
+piped_lo, piped_hi = piped
 span_p, hist_p, per_p = region(piped_lo, piped_hi)
-mid = n_fw // 3
-span_s, hist_s, per_s = region(ends[mid] + 1, ends[mid + steps] + 1)
+span_s, hist_s, per_s = region(*single)
 for tag, span, hist in (('single-stream region', span_s, hist_s), ('pipelined region', span_p, hist_p)):
     tot = sum(hist.values())
     print(f'{tag}: {span / steps / 1e6:.3f} ms per step; kernels in flight 0 / 1 / 2 / 3+: ' +
@@ -60,6 +62,7 @@ for k in sorted(per_s, key=lambda k: -per_s[k][1]):
     print(f'{k:46s} {a[0] / steps:5.1f} {a[1] / max(a[0], 1) / 1e3:8.1f} {b[1] / max(b[0], 1) / 1e3:8.1f}')
 print('sum of kernel durations per step: single %.3f ms, pipelined %.3f ms' % (
     sum(v[1] for v in per_s.values()) / steps / 1e6, sum(v[1] for v in per_p.values()) / steps / 1e6))
+print('queues of the pipelined region:', dict(collections.Counter(r.get('Queue_Id', '?') for r in rows[piped_lo:piped_hi])))
 print('timeline (pipelined region, us from the first row): start, duration, queue, kernel')
 base = int(rows[piped_lo]['Start_Timestamp'])
 for r in rows[piped_lo:piped_lo + nline]:
