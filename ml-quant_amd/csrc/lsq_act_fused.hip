@@ -990,6 +990,11 @@ static __device__ __forceinline__ void resolve_wslot(FusedLds* lds, unsigned n, 
   const double ps = sl.p0;
   unsigned* const wk = lds->a.w.arena[s];
   const unsigned succ_k = lds->a.w.succ[s];
+  // (the keys of a fine bin share one binade: value = 2^sc * mantissa, so the sums of the keys below a key are sums of 24-bit
+  //  integers -- at most 128 of them: 32 bits -- converted and scaled once; the same numbers as fp64 sums of the values)
+  const unsigned k0bin = lds->args.win_k0 + (sl.bin << lds->args.win_sh);
+  const unsigned hidden = (k0bin >> 23) ? (1u << 23) : 0u;
+  const double unit = __longlong_as_double((long long)(((k0bin >> 23) ? (int)(k0bin >> 23) - 150 : -149) + 1023) << 52);
   struct R {
     unsigned key, rank, below, eq;
     double bsum, psum;
@@ -998,7 +1003,7 @@ static __device__ __forceinline__ void resolve_wslot(FusedLds* lds, unsigned n, 
     R r;
     r.key = idx < cc ? wk[idx] : kNoKey;
     r.rank = r.below = r.eq = 0u;
-    r.bsum = r.psum = 0.0;
+    unsigned bs = 0u, psm = 0u;
     for (unsigned j0 = 0; j0 < cc; j0 += 4u) {
       unsigned kj[4];
 #pragma unroll
@@ -1006,15 +1011,17 @@ static __device__ __forceinline__ void resolve_wslot(FusedLds* lds, unsigned n, 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const unsigned j = j0 + (unsigned)q;
-        const double vj = (double)key_value(kj[q]);
+        const unsigned mj = (kj[q] & 0x7FFFFFu) | hidden;
         const bool lt = kj[q] < r.key, e = kj[q] == r.key;
         r.below += lt ? 1u : 0u;
         r.eq += e ? 1u : 0u;
-        if (lt) r.bsum += vj;
-        if (lt || (e && j <= idx)) r.psum += vj;
-        if (lt || (e && j < idx)) ++r.rank;
+        bs += lt ? mj : 0u;
+        psm += (lt || (e && j <= idx)) ? mj : 0u;
+        r.rank += (lt || (e && j < idx)) ? 1u : 0u;
       }
     }
+    r.bsum = (double)bs * unit;
+    r.psum = (double)psm * unit;
     return r;
   };
   auto test = [&](const R& r, unsigned idx) {    // (after the keys were rewritten in sorted order)

@@ -39,6 +39,8 @@
 // 64-byte segments of the NCHW output.  Every barrier is LDS-only (lds_barrier): the output stores and the prefetched
 // patch of the next chunk stay in flight across them.
 
+#include <type_traits>
+
 #include "lsq_common.h"
 
 // The waves of a workgroup talk to each other through LDS only (patch, horizontal maxima, carry); __syncthreads() would also
@@ -236,19 +238,25 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       if (ck + 1 < chunks) request(ck + 1, 0, pre);
     }
 
-    // ---- this wave's conv rows of the chunk
-    for (int q = q0; q < kCR; q += 2) {
-      const int cr = cr0 + q;
-      if (cr < 0 || cr >= a.Hc) continue;                      // (wave-uniform) a padding row of the pool
+    // ---- this wave's conv rows of the chunk.  PAIR (the last chunk of a row when at most 16 of its 32 columns exist: 112 = 3.5
+    // x 32): one tile holds TWO of the wave's rows x 16 columns instead of one row x 32 -- pixels 0..15 row qA, 16..31 row qB --
+    // so the half-empty chunk costs half the MFMAs, operand reads and maxima (round 5: an eighth of the kernel's row work).
+    auto rows = [&](int qA, int qB, auto pair_tag) {
+      constexpr bool PAIR = decltype(pair_tag)::value;
+      const bool okA = cr0 + qA >= 0 && cr0 + qA < a.Hc;
+      const bool okB = PAIR && qB < kCR && cr0 + qB >= 0 && cr0 + qB < a.Hc;
+      if (!okA && !okB) return;                                // (wave-uniform) padding rows of the pool
       f32x16 acc0 = {}, acc1 = {};        // leading products; all cross terms (<= 2^-8 of them: summed apart)
-      // B fragments: the reads of step s + 1 are issued before the MFMAs of step s (two register sets); the
+      // pixel fragments: the reads of step s + 1 are issued before the MFMAs of step s (two register sets); the
       // scheduling barriers keep it at two -- left alone, the scheduler hoists several steps' reads and spills
       constexpr int kDepth = 2;           // register sets of pixel fragments (three and four measured the same: round 5)
       Frag bf[kDepth][SPLIT];
+      const int ql = PAIR ? (xl_ < 16 ? qA : min(qB, kCR - 1)) : qA;       // the lane's conv row and column inside the chunk
+      const int xc = PAIR ? (xl_ & 15) : xl_;
       auto load_b = [&](int s, int which) {
         const int rr2 = min(2 * s + g, 20);
         const int kh = rr2 / 3, c = rr2 - kh * 3;
-        const int off = ((c * kIR + 2 * q + kh) * kIC) / 2 + xl_;   // dword index: 2 * x bf16 = x dwords
+        const int off = ((c * kIR + 2 * ql + kh) * kIC) / 2 + xc;   // dword index: 2 * x bf16 = x dwords
 #pragma unroll
         for (int i = 0; i < SPLIT; ++i)
 #pragma unroll
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
         }
       }
       // The MFMA operands are (pixels, weights): D[pixel][out-channel], so a lane holds ONE out-channel (mt * 32 + lane % 32)
-      // and sixteen pixels x = (reg & 3) + 8 (reg >> 2) + 4 g of the chunk -- groups of four consecutive columns.  The
+      // and sixteen pixels x = (reg & 3) + 8 (reg >> 2) + 4 g of the tile -- groups of four consecutive columns.  The
       // horizontal 3-max with stride 2 is then mostly lane-local: of a group [4k, 4k + 3] the centre 4k + 2 needs the
       // group's own three last columns, the centre 4k the column in front of the group, which the OTHER lane half holds
       // (groups alternate between the halves): one v_permlane32_swap per group.  44 VALU instructions per row and tile
@@ -291,11 +299,16 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       for (int reg = 0; reg < 16; ++reg) v[reg] = HALF ? fmaf(acc1[reg], 1.f / kLoScale, acc0[reg]) : acc1[reg] + acc0[reg];
       if (!full) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) v[reg] = 32 * ck + (reg & 3) + 8 * (reg >> 2) + 4 * g < a.Wc ? v[reg] : ninf;
+        for (int reg = 0; reg < 16; ++reg) {
+          const int x = (reg & 3) + 8 * (reg >> 2) + 4 * g;    // pixel of the tile; PAIR: column x & 15 of row qA (x < 16) / qB
+          v[reg] = 32 * ck + (PAIR ? (x & 15) : x) < a.Wc ? v[reg] : ninf;
+        }
       }
-      float* const cw = &lds.carry[q][mt][0][0];               // 32 floats per (row, tile): column 31 of the previous chunk
-      float prev0 = 0.f;
-      if (g == 0) prev0 = cw[xl_];
+      float prevA = 0.f, prevB = 0.f;                          // column 31 of the previous chunk (32 floats per row and tile)
+      if (g == 0) {
+        prevA = lds.carry[qA][mt][0][xl_];
+        if (PAIR) prevB = lds.carry[min(qB, kCR - 1)][mt][0][xl_];
+      }
       float lo_from_hi[4], hi_from_lo[4];
 #pragma unroll
       for (int G = 0; G < 4; ++G) {
@@ -307,12 +320,21 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       const int ch = mt * 32 + xl_;
 #pragma unroll
       for (int G = 0; G < 4; ++G) {
-        const float before = g ? hi_from_lo[G] : (G ? lo_from_hi[G ? G - 1 : 0] : prev0);     // column 8 G + 4 g - 1
-        const float ca = fmaxf(fmaxf(before, v[4 * G]), v[4 * G + 1]);                           // pooled column 4 G + 2 g
-        const float cb = fmaxf(fmaxf(v[4 * G + 1], v[4 * G + 2]), v[4 * G + 3]);                 // pooled column 4 G + 2 g + 1
-        *reinterpret_cast<float2*>(&lds.hbuf[q][ch][4 * G + 2 * g]) = make_float2(ca, cb);
+        const bool second = PAIR && G >= 2;                    // (compile time) the group belongs to row qB
+        const bool first_of_row = G == 0 || (PAIR && G == 2);
+        const float before = g ? hi_from_lo[G] : (first_of_row ? (second ? prevB : prevA) : lo_from_hi[G ? G - 1 : 0]);
+        const float ca = fmaxf(fmaxf(before, v[4 * G]), v[4 * G + 1]);                           // pooled column 4 G' + 2 g
+        const float cb = fmaxf(fmaxf(v[4 * G + 1], v[4 * G + 2]), v[4 * G + 3]);                 // pooled column 4 G' + 2 g + 1
+        const int Gc = PAIR ? (G & 1) : G;
+        if (second ? okB : okA)
+          *reinterpret_cast<float2*>(&lds.hbuf[second ? min(qB, kCR - 1) : qA][ch][4 * Gc + 2 * g]) = make_float2(ca, cb);
       }
-      if (g == 1) cw[xl_] = v[15];                             // column 31, for the next chunk (this wave's own: no barrier)
+      if (!PAIR && g == 1) lds.carry[qA][mt][0][xl_] = v[15];  // column 31, for the next chunk (this wave's own: no barrier)
+    };
+    if (a.Wc - 32 * ck <= 16) {                                // (uniform)
+      for (int q = q0; q < kCR; q += 4) rows(q, q + 2, std::true_type{});
+    } else {
+      for (int q = q0; q < kCR; q += 2) rows(q, q, std::false_type{});
     }
     SCLK();
     STEM_BARRIER();
