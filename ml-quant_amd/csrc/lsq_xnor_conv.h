@@ -24,6 +24,8 @@ struct ConvArgs {
   const float* slope;                  // PReLU slope(s): [1] (LSQ_ACT_PRELU) or [O] (LSQ_ACT_PRELU_CHANNEL)
   const float* res_pre;                // [N][O][Ho][Wo] or null
   const float* res_post;
+  int res_stream;                      // the residual operand is read with the non-temporal hint: it and the output together exceed the
+                                       // Infinity Cache and this is its last use (set by the entry point, kStreamBytes)
   int dbg_no_corr;                     // tuning builds only
   // ---- chained 1-bit layers (lsq_xnor_conv2d_chain): the NEXT layer's ls-1 quantizer in this layer's epilogue, and this
   // layer's activation scale from the exact row sum the PREVIOUS layer's epilogue left
@@ -38,6 +40,13 @@ struct ConvArgs {
   int nq_Hp, nq_Wp, nq_ph, nq_pw;
   int tap_xoff[64];                    // (kh*dil_h)*Wp + kw*dil_w per tap
 };
+
+// A block's tensors go from kernel to kernel through the 256 MiB Infinity Cache.  Where a launch reads a tensor for the last time
+// while it writes one of the same size and the two do not fit together (the 56 x 56 layers at batch 256: 205 MB each), the dead
+// tensor's loads carry the non-temporal hint so that the new lines push out consumed ones instead of lines the launch (or the
+// next quantizer) still needs: measured on the ResNet-18 step, xnor conv 88 -> 86 us and the quantizer BEHIND it 93 -> 89 us per
+// 56 x 56 layer; on tensors that do fit the hint costs 2-5 us per launch (28 x 28: 61 -> 67 us), hence the threshold.
+constexpr long long kInfinityCacheBytes = 256ll << 20;
 
 constexpr int kXnorMfmaNotEligible = 1;
 // One launch (one weight plane x kx <= 2 activation planes) on the matrix cores; kXnorMfmaNotEligible when the

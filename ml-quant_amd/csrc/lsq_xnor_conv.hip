@@ -283,6 +283,7 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
   a.slope = act_slope;
   a.res_pre = res_pre;
   a.res_post = res_post;
+  a.res_stream = 2ll * 4 * (long long)g->N * g->O * Ho * Wo > kInfinityCacheBytes;
   const bool chained = x_units != nullptr || next != nullptr;
   if (chained) {
     // chained 1-bit layers run on the integer-MFMA kernel only (3x3, C in {64, 128, 256, 512}); one activation plane

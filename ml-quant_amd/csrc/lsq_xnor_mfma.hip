@@ -261,8 +261,13 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       xs[0] = (float)(((double)a.xunits[ln] * a.xunit) / a.xM) * 0.03125f;
     if (want_pre || want_post) {
       const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
+      if (a.res_stream) {           // (uniform) last use of a tensor that does not fit the Infinity Cache next to the output: lsq_xnor_conv.h
 #pragma unroll
-      for (int i = 0; i < 16; ++i) rv[i] = (rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+        for (int i = 0; i < 16; ++i) rv[i] = __builtin_nontemporal_load(rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo + yoff);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[i] = (rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) rv[i] = 0.f;

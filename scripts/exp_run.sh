@@ -1,3 +1,7 @@
-LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/sq/liblsq_hip.so python -m pytest tests/ -q -m gpu -k "stem" 2>&1 | tail -2
-LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/sqc/liblsq_hip.so python scripts/stem_clocks.py 2>&1 | grep "split 22"
-for r in 1 2 3; do echo "== base"; python scripts/stem_time.py 2>&1 | grep -v amdgpu | tail -1; echo "== sq"; LSQ_HIP_LIB=$PWD/ml-quant_amd/lib_exp/sq/liblsq_hip.so python scripts/stem_time.py 2>&1 | grep -v amdgpu | tail -1; done
+for r in 1 2 3; do for t in old base st1; do
+  if [ $t = base ]; then L=$PWD/ml-quant_amd/lib/liblsq_hip.so; else L=$PWD/ml-quant_amd/lib_exp/$t/liblsq_hip.so; fi
+  LSQ_HIP_LIB=$L python bench.py --no-configs --cpu-sample 0 --min-seconds 2 --detail gpurun_out/det_${t}_$r.json 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('$t', round(d['value']), 'single', round(d['single_stream']['value']), 'quant', round(r['quantizer']['ms_per_step'],4), 'xnor', round(r['xnor_conv']['ms_per_step'],4))"
+done; done

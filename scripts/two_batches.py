@@ -15,6 +15,17 @@ act = sys.argv[1] if len(sys.argv) > 1 else 'ls-2'
 dev = torch.device('cuda', 0)
 model = bench.build_model(bench.imagenet_arch(act, 3 if act == 'ls-2' else 2), dev)
 xs = [torch.randn(256, 3, 224, 224, device=dev) for _ in range(3)]
+if os.environ.get('LSQ_EXP_NO_FC'):                 # (experiment: the forward ends with the pooling kernel)
+    if os.environ['LSQ_EXP_NO_FC'] == 'all':
+        model.linear_classifier = torch.nn.Identity()
+    else:
+        model.linear_classifier[2] = torch.nn.Identity()
+if os.environ.get('LSQ_EXP_FUSED_MODE'):           # (experiment: lsq_debug_fused_mode, e.g. 4 = the round-2 solve, kernels without a stack)
+    from quant import _hip
+    _hip.lib().lsq_debug_fused_mode(int(os.environ['LSQ_EXP_FUSED_MODE']))
+if os.environ.get('LSQ_EXP_DUMMY_FIRST'):          # (experiment: a one-workgroup kernel in front of every forward)
+    _fwd, _d = model.forward, torch.zeros(64, device=dev)
+    model.forward = lambda x: (_d.add_(1.0), _fwd(x))[1]
 
 
 def timed(nstreams, steps=60):
