@@ -38,13 +38,17 @@ python scripts/kbench.py > $o/${tag}_kbench.txt 2>&1
 python scripts/ls1_chain.py > $o/${tag}_ls1_chain.txt 2>&1
 python scripts/xnor_variants.py > $o/${tag}_xnor_variants.txt 2>&1
 python scripts/kbench.py --fold > $o/${tag}_kbench_bnfold.txt 2>&1
+# the same launches as a network sees them: caches emptied in front of every launch, the launch's input read back in
+python scripts/kbench.py --evict 600 --retouch > $o/${tag}_kbench_cold.txt 2>&1
 # round 5: what runs under what when consecutive steps alternate between two HIP streams (the headline's issue order)
 rm -rf $o/prof_ov
 rocprofv3 --kernel-trace --output-format csv -d $o/prof_ov -- python bench.py --steps 30 --warmup 5 --min-seconds 0 --cpu-sample 0 --no-configs --no-roofline --streams 2 > $o/prof_ov.log 2>&1
 python scripts/overlap_trace.py $(ls -t $o/prof_ov/*/*kernel_trace.csv | head -1) 10 110 > $o/${tag}_two_stream_overlap.txt 2>&1
+python scripts/queue_gaps.py $(ls -t $o/prof_ov/*/*kernel_trace.csv | head -1) 150 0 > $o/${tag}_queue_gaps.txt 2>&1
 rm -rf $o/prof_ov
 # what the free-running parity assertions observe on this box, next to their derived limits
 LSQ_RECORD_PARITY=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round4.py -q -m gpu > $o/parity_tests.log 2>&1
 cp $o/free_running_observed.json $o/${tag}_free_running_parity.json
+scripts/pmc_icache.sh $o/${tag}_pmc_icache.txt > $o/pmc_icache.log 2>&1
 python scripts/sched_variants.py 40 > $o/${tag}_sched_variants.txt 2>&1
 head -3 $o/${tag}_rocprofv3_per_step_summary.csv; cut -c1-300 $o/${tag}_bench_n1_ls2.json; cut -c1-160 $o/${tag}_bench_n1_fpact.json

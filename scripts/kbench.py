@@ -21,6 +21,9 @@ SHAPES = [  # (C, H, O, stride, count in ResNet-18)
     (256, 14, 256, 1, 3), (256, 14, 512, 2, 1), (512, 7, 512, 1, 3)]
 
 
+PRE = None       # --evict: run in front of every timed launch, outside the events (cold L2 / Infinity Cache, as inside a network)
+
+
 def timeit(fn, iters):
     for _ in range(3):
         fn()
@@ -28,6 +31,8 @@ def timeit(fn, iters):
     evs = []
     for _ in range(iters):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if PRE is not None:
+            PRE()
         s.record()
         fn()
         e.record()
@@ -48,9 +53,28 @@ def main():
     ap.add_argument('--xnor-popcount', action='store_true', help='every XNOR convolution through the popcount kernel')
     ap.add_argument('--streaming', action='store_true', help='quantizer through the streaming sweeps (test hook lsq_debug_force_streaming)')
     ap.add_argument('--forced', action='store_true', help='quantizer with the caller\'s scales (moving-average inference): no solve')
+    ap.add_argument('--evict', type=int, default=0, help='MB streamed through the caches in front of every timed launch (a kernel '
+                    'inside a network finds its code and tables neither in L2 nor in the instruction caches)')
+    ap.add_argument('--prewarm-code', action='store_true', help='with --evict: the same kernel on 8 samples right in front of the timed launch (its code, tables and weights back in every L2)')
+    ap.add_argument('--retouch-weights', action='store_true', help='with --evict --retouch: also the packed weights, tap sums and scales of the convolution')
+    ap.add_argument('--retouch', action='store_true', help='with --evict: read the quantizer input / the planes once more after the '
+                    'eviction (the producer inside a network has just written them)')
     args = ap.parse_args()
     _hip.xnor_impl(args.xnor_popcount)
     dev = 'cuda:0'
+    global PRE
+    touch = []
+    warm = []
+    if args.evict:
+        junk = torch.empty(args.evict << 18, device=dev)
+
+        def PRE():
+            junk.add_(1.0)
+            if args.prewarm_code and warm:
+                warm[0]()
+            if args.retouch:
+                for t in touch:
+                    (t.view(-1)[:t.numel() // 4 * 4].view(-1, 4).sum() if t.numel() >= 4096 else t.sum())
     sch = {'ls-1': (1, 1), 'ls-2': (2, 2), 'ls-T': (3, 2), 'gf-2': (4, 2)}[args.scheme]
     n = args.batch
     tot_q = tot_c = tot_f = 0.0
@@ -74,9 +98,17 @@ def main():
         if args.fold:
             pre = ((0.5 + torch.rand(c, device=dev)).contiguous(), (torch.randn(c, device=dev) * 0.3).contiguous())
         forced = (torch.rand((k, n), device=dev) + 0.5).contiguous() if args.forced else None
+        g8 = _hip.make_geom(8, c, h, h, o, 3, 3, (stride, stride), (1, 1), (1, 1), 1)
+        planes8 = torch.zeros(k * _hip.act_plane_words(g8), dtype=torch.int64, device=dev)
+        scales8, y8, x8 = torch.empty((k, 8), device=dev), torch.empty((8, o, ho, wo), device=dev), x[:8].clone()
+        touch[:] = [x]
+        warm[:] = [lambda: _hip.act_quant(x8, g8, sch[0], k, 3, 3.0, planes8, scales8, pre=pre, forced=None if forced is None else forced[:, :8].contiguous())]
         with _hip.debug_switches(force_streaming=args.streaming):
             tq = timeit(lambda: _hip.act_quant(x, g, sch[0], k, 3, 3.0, planes, scales, pre=pre, forced=forced), args.iters)
+        touch[:] = [planes] + ([wbits.view(torch.float32) if wbits.dtype != torch.float32 else wbits, wsum.view(torch.float32), wsc, bias] if args.retouch_weights else [])
+        warm[:] = [lambda: _hip.xnor_conv2d(planes8, k, scales8, wbits, wsum, wsc, bias, g8, y8)]
         tc = timeit(lambda: _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wsc, bias, g, y), args.iters)
+        warm[:] = []
         wprep = _hip.signw_prepare_weight(wbits, 1, g)      # (the prepared weight image: the fast path, as the modules use it)
         tf = timeit(lambda: _hip.signw_conv2d(x, 2.0, wbits, wsc, bias, g, y, wprep=wprep), args.iters)
         m = c * h * h
