@@ -60,6 +60,19 @@ def _weight_residual_planes(weight: torch.Tensor, plane_scales: torch.Tensor) ->
     return out
 
 
+_CONSTANTS = {}
+
+
+def _constants(c: int, o: int, device):
+    """(ones [1, c], zeros [o]) on ``device``: read-only operands of the input-gradient convolutions, made once."""
+    key = (c, o, device)
+    t = _CONSTANTS.get(key)
+    if t is None:
+        t = _CONSTANTS[key] = (torch.ones((1, c), dtype=torch.float32, device=device),
+                               torch.zeros((o,), dtype=torch.float32, device=device))
+    return t
+
+
 class _QuantConv2dStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, conv):
@@ -83,7 +96,16 @@ class _QuantConv2dStep(torch.autograd.Function):
             xscales = None
         else:
             k = xq_mod.n_planes
-            planes = torch.zeros((k * _hip.act_plane_words(geom),), dtype=torch.int64, device=x.device)
+            # the plane workspace is the module's, one per input shape and launch stream as in eval mode (zero halo written
+            # once, the kernels rewrite the interior); the scales are saved for backward and stay a tensor of this step
+            key = ('train_planes', geom.key()[:4], geom.pad_h, geom.pad_w, k, x.device, _hip.stream_ptr(x.device))
+            planes = conv._hip_cache.get(key)
+            if planes is None:
+                planes = torch.zeros((k * _hip.act_plane_words(geom),), dtype=torch.int64, device=x.device)
+                stale = [kk for kk in list(conv._hip_cache) if isinstance(kk, tuple) and kk[0] == 'train_planes']
+                for kk in stale[:max(0, len(stale) - 3)]:
+                    conv._hip_cache.pop(kk, None)
+                conv._hip_cache[key] = planes
             xscales = torch.empty((k, n), dtype=torch.float32, device=x.device)
             forced = xq_mod._forced_scales
             forced = None if forced is None else xq_mod.plane_scales(forced).to(device=x.device, dtype=torch.float32).contiguous()
@@ -131,8 +153,7 @@ class _QuantConv2dStep(torch.autograd.Function):
                 gin[:, :, ::s, ::s][:, :, :gy.shape[2], :gy.shape[3]] = gy
             tgeom = _hip.make_geom(n, o, gin.shape[2], gin.shape[3], c, kh, kw, (1, 1), (kh - 1 - ph, kw - 1 - pw), (1, 1), 1)
             assert _hip.out_hw(tgeom) == (h, w), (_hip.out_hw(tgeom), h, w)
-            ones = torch.ones((1, c), dtype=torch.float32, device=x.device)
-            zeros = torch.zeros((o,), dtype=torch.float32, device=x.device)
+            ones, zeros = _constants(c, o, x.device)
             gxq = None
             for r, u in zip(_weight_residual_planes(weight.detach(), wscales), wscales):
                 wt = r.permute(1, 0, 2, 3).flip(2, 3).contiguous()              # [C, O, KH, KW], taps mirrored
