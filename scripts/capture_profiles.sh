@@ -31,7 +31,7 @@ for s in "64 56 64 1 4" "64 56 128 2 1" "128 28 128 1 3" "128 28 256 2 1" "256 1
 done
 scripts/pmc_kernel.sh stem_conv_pool stem python scripts/stem_one.py > $o/pmc_stem.txt 2>&1
 python scripts/pmc_sq_table.py $o/${tag}_pmc_sq.json $specs lsq_stem_conv_pool:224x224:1:stem_conv_pool:$o/pmc_stem > $o/${tag}_pmc_sq.txt 2>&1
-for u in valu_rates launch_overhead lds_atomics; do
+for u in valu_rates launch_overhead lds_atomics l2_retention; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/$u.hip -o /tmp/$u 2> $o/$u.build.log && /tmp/$u > $o/${tag}_ubench_$u.txt 2>&1
 done
 python scripts/kbench.py > $o/${tag}_kbench.txt 2>&1
