@@ -1,1 +1,2 @@
-for a in "--evict 600 --retouch" "--evict 600 --retouch --prewarm-code"; do echo "== kbench $a"; python scripts/kbench.py $a 2>&1 | grep -v amdgpu | cut -c1-110; done
+# scratch: the command file of the last experiment run through gpurun (scripts/exp_build.sh / exp_file.sh build the libraries under
+# ml-quant_amd/lib_exp/, LSQ_HIP_LIB selects one)
