@@ -377,7 +377,8 @@ def main():
     ap.add_argument('--min-seconds', type=float, default=5.0,
                     help='repeat the bracket of --steps timed steps until this much time has been timed (headline region)')
     ap.add_argument('--batch', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--cpu-sample', type=int, default=256, help='batch of the cpu_baseline leg (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=64,
+                    help='batch of the cpu_baseline leg (0 = skip); 64 = the bounded sample SURVEY 8(d) names (B = 64)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the legs of the other single-GPU configs')
     ap.add_argument('--act', default='ls-2', choices=['ls-1', 'ls-2', 'ls-T', 'gf-2', 'fp'],
@@ -529,9 +530,17 @@ def main():
                 for (name, _tag), v in by_shape.items():
                     table[name] = tuple(a + b for a, b in zip(table.get(name, (0, 0.0, 0, 0, 0)), v))
                 _hip.enable_timing(True, only=[k for k in PATH_KERNELS if k in table])
-            per = max(1, args.steps // 10)
-            s_elapsed, s_reps, s_rep_ms = bracket(lambda n: run_single(n, per if roofline else 0), min(args.min_seconds, 1.5))
+            # the one-stream figure is timed on an UNINSTRUMENTED bracket (no event pairs inside: the same footing as the
+            # headline region); the per-kernel events then come from a separate, untimed run of kSampleSteps steps in which
+            # every kSampleEvery-th step carries them -- a fixed rate, whatever --steps is (round 5 tied it to --steps / 10: under
+            # the driver's --steps 20 every second step of the timed region carried 32 event pairs)
+            _hip.pause_timing(True)
+            s_elapsed, s_reps, s_rep_ms = bracket(lambda n: run_single(n, 0), min(args.min_seconds, 2.0))
+            _hip.pause_timing(False)
             if roofline:
+                kSampleEvery, kSampleSteps = 20, 100
+                run_single(kSampleSteps, kSampleEvery)
+                sync()
                 timed_table = _hip.drain_timing()
                 _hip.enable_timing(False)
         single = {'value': world * args.batch * s_reps * args.steps / s_elapsed, 'unit': 'images/sec', 'steps_timed': s_reps * args.steps,
@@ -614,8 +623,8 @@ def main():
             worst = min(path, key=lambda k: path[k]['frac'])                # the path kernel furthest below ITS roofline
             out['roofline'] = dict(slim(path[worst]), name=worst,
                                    measured='one stream (each kernel alone on the chip, as in the rocprofv3 summaries under profiles/): HIP '
-                                            'events around every launch of the kernel in the first step of every group of steps of the '
-                                            'single_stream region; roofline = the path kernel with the lower fraction, both follow')
+                                            'events around every launch of the kernel in every 20th of 100 one-stream steps run behind the '
+                                            '(uninstrumented) single_stream region; roofline = the path kernel with the lower fraction, both follow')
             for k, e in path.items():
                 out['roofline'][k] = slim(e)
                 if 'secondary' in e:
@@ -684,6 +693,11 @@ def main():
                                   if kk in ('batch', 'value', 'ms_per_step', 'launch', 'reference_cpu_images_per_sec_survey')}
                               for k, v in cfg.items()}
             for k, v in cfg.items():
+                if v.get('roofline', {}).get('bound') == 'mfma':           # BASELINE config 3 asks for the MFMA utilisation in the line
+                    out['configs'][k]['dominant_kernel'] = v['roofline']['kernel']
+                    out['configs'][k]['mfma_frac_of_peak'] = round(v['roofline']['frac'], 4)
+                    out['configs'][k]['mfma_busy_frac'] = (None if v['roofline'].get('mfma_busy_frac') is None
+                                                           else round(v['roofline']['mfma_busy_frac'], 4))
                 if 'graph_replay' in v:
                     out['configs'][k]['graph_replay_value'] = round(v['graph_replay']['value'], 1)
             out['configs_note'] = 'one stream, eager eval forward, images/sec, inputs resident in HBM; full tables: --detail'
