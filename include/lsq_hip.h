@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQ_ABI_VERSION 10
+#define LSQ_ABI_VERSION 11
 
 /* fused non-linearity of the convolution epilogues (quant/models/resnet.py non_linearity_map) */
 #define LSQ_ACT_NONE 0
@@ -80,6 +80,30 @@ typedef struct lsq_conv_geom {
   int32_t groups;
 } lsq_conv_geom;
 
+/*
+ * Layouts of fp32 activation tensors (ABI v11).
+ *  LSQ_LAYOUT_NCHW    [N][C][H][W], what the reference's modules produce.
+ *  LSQ_LAYOUT_SPLIT3  "three-stream rows": a sample's row of M = C*H*W values (flat NCHW index e = c*H*W + h*W + w) is
+ *                     stored as three streams of S = lsq_split3_stream_floats(C, H, W) floats, element e at
+ *                     (e % 3) * S + e / 3; rows are 3*S floats apart.  Why: the v1 search of quantizer_ls_2 /
+ *                     quantizer_ls_ternary looks at every third element of the row (quant/binary/quantization.py:63,
+ *                     skip = 3; optimal.py:121-155) -- in NCHW that is a third of every cache line, i.e. a full read of
+ *                     the row; here it is stream 0, one contiguous third.  A tensor that goes from a convolution's
+ *                     epilogue to the next layer's quantizer (and to a later epilogue as a residual operand) can stay in
+ *                     this layout from its producer to its last consumer: lsq_xnor_conv2d_layout writes and reads it,
+ *                     lsq_act_quant_layout and lsq_pointwise_conv_layout read it.  Needs H*W % 3 == 1 (every layer of the
+ *                     reference's ResNets: 56^2, 28^2, 14^2, 7^2, 32^2 ... 4^2), so that e % 3 = (c + pixel) % 3.
+ *                     Values are the NCHW tensor's, bit for bit; only their addresses differ.
+ */
+#define LSQ_LAYOUT_NCHW 0
+#define LSQ_LAYOUT_SPLIT3 1
+/* floats per stream of a SPLIT3 row (a multiple of 32, at least ceil(C*H*W / 3) + 8); -1 when H*W % 3 != 1 */
+int64_t lsq_split3_stream_floats(int64_t C, int64_t H, int64_t W);
+/* which operands of a call with geometry g may be SPLIT3: bit 0 -- the input of lsq_act_quant_layout(scheme, skip 3, no
+ * forced scales, clamp > 0); bit 1 -- y of lsq_xnor_conv2d_layout with kx activation planes; bit 2 -- its residual operands;
+ * bit 3 -- x of lsq_pointwise_conv_layout for a 1x1 convolution of stride g->stride_h over g's input */
+int lsq_layout_support(const lsq_conv_geom* g, int scheme, int kx);
+
 /* number of uint64 words of ONE activation plane for `g` (N * Gt * Hp * Wp) */
 int64_t lsq_act_plane_words(const lsq_conv_geom* g);
 /* number of uint64 words of ONE weight plane (KH*KW * Gg * O) */
@@ -114,6 +138,13 @@ int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int
                   float clamp_alpha, const float* pre_scale, const float* pre_shift,
                   const float* forced, uint64_t* planes, float* scales,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* lsq_act_quant for an input in `x_layout` (LSQ_LAYOUT_*); SPLIT3: LS2 / LST without forced scales, skip 3, clamp_alpha > 0,
+ * C a multiple of 64 per group, LSQ_E_UNSUPPORTED otherwise.  Planes and scales are those of the NCHW call, bit for bit. */
+int lsq_act_quant_layout(const float* x, int x_layout, const lsq_conv_geom* g, int scheme, int k, int skip,
+                         float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                         const float* forced, uint64_t* planes, float* scales,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Bytes of scratch the LS2 / LST scale solve needs for `rows` rows (slot records handed from the
  * histogram sweep to the solve kernel).  Not needed (may be NULL / 0) for LS1, GF or forced scales. */
@@ -209,6 +240,15 @@ int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xscales,
                     const float* wscales, const float* bias, const lsq_conv_geom* g,
                     int act, const float* act_slope, const float* res_pre, const float* res_post,
                     float* y, void* stream);
+
+/* lsq_xnor_conv2d with y in `y_layout` and res_pre / res_post in `res_layout` (LSQ_LAYOUT_*).  SPLIT3 operands: the
+ * integer-MFMA kernel's 3x3 geometries over 64 or 128 channels with two activation planes (lsq_layout_support), else
+ * LSQ_E_UNSUPPORTED.  Same values as the NCHW call. */
+int lsq_xnor_conv2d_layout(const uint64_t* xplanes, int kx, const float* xscales,
+                           const uint64_t* wbits, const int32_t* wsum, int kw_planes,
+                           const float* wscales, const float* bias, const lsq_conv_geom* g,
+                           int act, const float* act_slope, const float* res_pre, const float* res_post, int res_layout,
+                           float* y, int y_layout, void* stream);
 
 /*
  * Full-precision activation x sign-weight convolution on bf16 MFMA (x split hi+lo):

@@ -25,6 +25,8 @@ struct FusedArgs {
   int win_sh;               // (k - win_k0) >> win_sh, 8192 bins up to the top of the clamp value's binade; 0: off
   const float* forced;      // [2][N] scales given by the caller (moving-average inference): no solve, planes only
   int* trace;               // test hook: chosen sorted position per row (lsq_debug_solver_trace), or null
+  int x_s3;                 // 0: rows in NCHW order; else S, the floats per stream of three-stream rows (LSQ_LAYOUT_SPLIT3):
+                            // element e of a row at (e % 3) * S + e / 3, rows 3 S floats apart (fused_act_quant_s3 only)
   int greedy;               // gf-2 (quantization.py:118-148 with k = 2): v1 = mean |x| instead of the solve; planes and
                             // v2 = mean |x - v1 b1| are the 2-bit least-squares scheme's
 };
@@ -33,5 +35,7 @@ constexpr int kFusedNotEligible = 1;   // the shape is left to the streaming thr
 
 // LSQ_OK, an hipError_t, or kFusedNotEligible (nothing launched).  skip is the reference's 3.
 int fused_act_quant(const FusedArgs& a, hipStream_t st);
+// the same for rows in the three-stream layout (a.x_s3 != 0; LS-2 / LS-T solve under a symmetric clamp, skip 3)
+int fused_act_quant_s3(const FusedArgs& a, hipStream_t st);
 
 }  // namespace lsq

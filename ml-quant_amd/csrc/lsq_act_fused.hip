@@ -43,8 +43,17 @@
 #ifndef LSQ_WIN_HIST
 #define LSQ_WIN_HIST 0
 #endif
+// This file is compiled TWICE (Makefile): as it is -- fused_act_quant, rows in NCHW order -- and with -DLSQ_FUSED_S3=1 --
+// fused_act_quant_s3, the same kernels for rows in the THREE-STREAM layout (LSQ_LAYOUT_SPLIT3, include/lsq_hip.h: element e
+// of the row at (e % 3) * S + e / 3).  There the sub-sample e % 3 == 0 of the v1 search (quantization.py:63, skip = 3) is
+// the first contiguous third of the row: pass 1 reads a third of the bytes (one float4 per four keys instead of three),
+// pass 2 reads all three streams -- 4/3 reads of the row instead of 2.  Keys go to the same registers in the same
+// order and pass 2 sums every pixel's |r| in the same channel order, so planes and scales are the NCHW kernels' bit for bit.
+#ifndef LSQ_FUSED_S3
+#define LSQ_FUSED_S3 0
+#endif
 namespace lsq {
-#ifdef LSQ_PHASE_CLOCKS
+#if defined(LSQ_PHASE_CLOCKS) && !LSQ_FUSED_S3
 __device__ long long g_fused_times[1024][16];    // constant-rate clock (100 MHz) at the phase marks of each workgroup
 #define FMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_fused_times[blockIdx.x][i] = (long long)wall_clock64(); } while (0)
 __device__ int g_win_stats[1024][4];             // windowed level 1: 1 solved / 2 fell back, flags, flagged groups, flagged fine bins
@@ -55,6 +64,8 @@ __device__ int g_win_stats[1024][4];             // windowed level 1: 1 solved /
 #define FMARK(i) do {} while (0)
 #endif
 namespace {
+
+constexpr bool kS3 = LSQ_FUSED_S3 != 0;        // rows in the three-stream layout (this translation unit's kernels)
 
 constexpr int kNzCap = 2048;                   // non-empty level-1 bins tested per chunk of the level-1 scan
 constexpr int kSlotCap = 64;                   // flagged level-1 bins per scan round (slot records)
@@ -349,7 +360,7 @@ static __device__ __forceinline__ void for_each_row_key(const FusedArgs& a, cons
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned j = min(j0 + (unsigned)u * kThreads, n - 1u);
-      v[u] = xrow[(long long)j * 3];
+      v[u] = kS3 ? xrow[j] : xrow[(long long)j * 3];     // (three-stream rows: the sub-sample is stream 0)
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -1538,14 +1549,43 @@ struct Pf {
 // those loads until most of the 256 KB of its workgroup have arrived -- measured: the phase behind the request grew by
 // exactly what pass 2 saved.  An eighth at a time (32 KB per CU) fits, and the copy runs meanwhile.
 static constexpr int kPfParts = 8;
+// Three-stream rows: where a lane's item -- VEC pixels p0, p0 + 3, ... (one class mod 3: consecutive floats of a stream) x
+// 64 channels -- finds channel c0 + cc: stream (u0 + cc) % 3 at rank (c0 + cc) h + (u0 + cc) / 3 with u0 = c0 + p0, i.e.
+// qb[cc % 3] + (cc / 3) (3 h + 1) from three per-lane pointers.
+struct S3Item {
+  const float* qb[3];
+  int step;                                                          // 3 h + 1 floats
+};
+static __device__ __forceinline__ S3Item s3_item(const FusedArgs& a, const float* __restrict__ xrow, int c0, int p0) {
+  const unsigned h = (unsigned)(a.H * a.W) / 3u, S = (unsigned)a.x_s3;
+  const unsigned u0 = (unsigned)(c0 + p0);
+  S3Item it;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const unsigned u = u0 + (unsigned)m, q = __umulhi(u, 0xAAAAAAABu) >> 1, r = u - 3u * q;
+    it.qb[m] = xrow + ((long long)r * S + (long long)(c0 + m) * h + q);
+  }
+  it.step = 3 * (int)h + 1;
+  return it;
+}
+// item index -> (channel word j, first pixel p0) of a three-stream row: per word 3 * PG items, PG = ceil(HW / (3 VEC))
+// groups of 3 VEC consecutive pixels, item (g, s) = pixels 3 VEC g + s + 3 v
+template <int VEC>
+static __device__ __forceinline__ void s3_decode(int item, int PG, int& j, int& p0) {
+  j = item / (3 * PG);
+  const int idx = item - j * 3 * PG;
+  const int g = idx / 3;
+  p0 = 3 * VEC * g + (idx - 3 * g);
+}
+
 template <int VEC, int K>
-static __device__ __forceinline__ void pass2_request_part(const float* __restrict__ q0, int HW, Pf<VEC>& pf) {
+static __device__ __forceinline__ void pass2_request_part(const float* __restrict__ q0, int HW, Pf<VEC>& pf, const S3Item* s3 = nullptr) {
   constexpr int L = Pf<VEC>::PB * Pf<VEC>::UB;                       // loads of the whole request
   constexpr int lo = K * L / kPfParts, hi = (K + 1) * L / kPfParts;
 #pragma unroll
   for (int i = lo; i < hi; ++i) {
     constexpr int UB = Pf<VEC>::UB;
-    const float* __restrict__ q = q0 + (long long)i * HW;
+    const float* __restrict__ q = kS3 ? s3->qb[i % 3] + (long long)(i / 3) * s3->step : q0 + (long long)i * HW;
     const int b = i / UB, u = i % UB;
     if constexpr (VEC == 4) {
       const float4 t = *reinterpret_cast<const float4*>(q);
@@ -1564,23 +1604,31 @@ template <int VEC>
 static __device__ __forceinline__ void pass2_request(const FusedArgs& a, const float* __restrict__ xrow, int item0, Pf<VEC>& pf,
                                                      unsigned parts) {
   const int HW = a.H * a.W;
-  const int PV = (HW + VEC - 1) / VEC;
+  const int PV = kS3 ? 3 * ((HW + 3 * VEC - 1) / (3 * VEC)) : (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
   if (item0 >= items) return;
-  const int j = item0 / PV;
-  const int p = (item0 - j * PV) * VEC;
+  int j, p;
+  if constexpr (kS3) {
+    s3_decode<VEC>(item0, PV / 3, j, p);
+  } else {
+    j = item0 / PV;
+    p = (item0 - j * PV) * VEC;
+  }
   const int grp = j / a.Gg;
   const int jj = j - grp * a.Gg;
   const int c0 = grp * a.cg + jj * 64;
   const float* __restrict__ q = xrow + (long long)c0 * HW + p;
-  if (parts & 1u) pass2_request_part<VEC, 0>(q, HW, pf);               // (compile-time masks at every call site)
-  if (parts & 2u) pass2_request_part<VEC, 1>(q, HW, pf);
-  if (parts & 4u) pass2_request_part<VEC, 2>(q, HW, pf);
-  if (parts & 8u) pass2_request_part<VEC, 3>(q, HW, pf);
-  if (parts & 16u) pass2_request_part<VEC, 4>(q, HW, pf);
-  if (parts & 32u) pass2_request_part<VEC, 5>(q, HW, pf);
-  if (parts & 64u) pass2_request_part<VEC, 6>(q, HW, pf);
-  if (parts & 128u) pass2_request_part<VEC, 7>(q, HW, pf);
+  S3Item s3v;
+  if constexpr (kS3) s3v = s3_item(a, xrow, c0, p);
+  const S3Item* s3 = kS3 ? &s3v : nullptr;
+  if (parts & 1u) pass2_request_part<VEC, 0>(q, HW, pf, s3);           // (compile-time masks at every call site)
+  if (parts & 2u) pass2_request_part<VEC, 1>(q, HW, pf, s3);
+  if (parts & 4u) pass2_request_part<VEC, 2>(q, HW, pf, s3);
+  if (parts & 8u) pass2_request_part<VEC, 3>(q, HW, pf, s3);
+  if (parts & 16u) pass2_request_part<VEC, 4>(q, HW, pf, s3);
+  if (parts & 32u) pass2_request_part<VEC, 5>(q, HW, pf, s3);
+  if (parts & 64u) pass2_request_part<VEC, 6>(q, HW, pf, s3);
+  if (parts & 128u) pass2_request_part<VEC, 7>(q, HW, pf, s3);
 }
 
 // full 64-channel groups: every channel index is a compile-time constant.  PRE: the caller may hold the first batches
@@ -1591,8 +1639,9 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
                                                     unsigned long long* __restrict__ prow0, unsigned long long* __restrict__ prow1,
                                                     int item0, int item_step, const Pf<VEC>* pre = nullptr, bool have_pre = false) {
   const int HW = a.H * a.W;
-  const int PV = (HW + VEC - 1) / VEC;
+  const int PV = kS3 ? 3 * ((HW + 3 * VEC - 1) / (3 * VEC)) : (HW + VEC - 1) / VEC;
   const int items = a.Gt * PV;
+  constexpr int PSTEP = kS3 ? 3 : 1;                     // pixel stride of a lane's VEC values
   const float alpha = a.alpha >= 0.f ? a.alpha : INFINITY;
   double acc = 0.0;
   // loads per batch; two batches in flight.  One pixel per lane (the short rows): all 64 channels at once --
@@ -1602,12 +1651,19 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
   constexpr int PB = Pf<VEC>::PB;
   auto one_item = [&](int item, auto first_tag) {
     constexpr bool FIRST = decltype(first_tag)::value;    // the batches b < PB are already in `pre`
-    const int j = item / PV;
-    const int p = (item - j * PV) * VEC;
+    int j, p;
+    if constexpr (kS3) {
+      s3_decode<VEC>(item, PV / 3, j, p);
+    } else {
+      j = item / PV;
+      p = (item - j * PV) * VEC;
+    }
     const int grp = j / a.Gg;
     const int jj = j - grp * a.Gg;
     const int c0 = grp * a.cg + jj * 64;
     const float* __restrict__ src = xrow + (long long)c0 * HW + p;
+    S3Item s3v;
+    if constexpr (kS3) s3v = s3_item(a, xrow, c0, p);
     const float* __restrict__ bs = bn_s + c0;      // (LDS copies of the folded batch norm)
     const float* __restrict__ bt = bn_t + c0;
     unsigned w0[VEC][2], w1[VEC][2];
@@ -1619,9 +1675,13 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
     }
     float buf[2][UB][VEC];
     const float* __restrict__ q = src + (FIRST ? (long long)PB * UB * HW : 0ll);   // running channel pointer (no table of 64 addresses)
-    auto load = [&](int which, int) {
+    auto load = [&](int which, int bb) {
 #pragma unroll
       for (int u = 0; u < UB; ++u, q += HW) {
+        if constexpr (kS3) {
+          const int cc = bb * UB + u;
+          q = s3v.qb[cc % 3] + (long long)(cc / 3) * s3v.step;
+        }
         if constexpr (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4*>(q);
           buf[which][u][0] = t.x; buf[which][u][1 % VEC] = t.y; buf[which][u][2 % VEC] = t.z; buf[which][u][3 % VEC] = t.w;
@@ -1663,8 +1723,8 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
     }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      acc += (double)facc[v];
-      const int pix = p + v;
+      const int pix = p + PSTEP * v;
+      if (!kS3 || pix < HW) acc += (double)facc[v];      // (three-stream rows: a value past the image belongs to the next channel)
       if (pix < HW) {
         const int h = pix / a.W;
         const int w = pix - h * a.W;
@@ -1770,7 +1830,7 @@ template <int U, int VEC, bool WIN>
 static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
-  const float* __restrict__ xrow = a.x + (long long)row * a.row_elems;
+  const float* __restrict__ xrow = a.x + (long long)row * (kS3 ? 3ll * a.x_s3 : a.row_elems);
   FMARK(0);
   for (int i = tid; i < L1_BINS; i += kThreads) lds->a.hist1[i] = 0ull;
   // windowed level-1 histogram (solve_windowed): fine bins over the binades below the clamp value, one bin per binade below them
@@ -1806,15 +1866,22 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
     // triples in flight per lane (more in flight measured slower: the histogram atomics of a batch overlap the
     // loads of the next one)
     constexpr int B = 3;
+    // three-stream rows: the four sub-sampled elements 12 jt + {0, 3, 6, 9} of a lane's step are ONE float4 of stream 0
+    // (ranks 4 jt .. 4 jt + 3) -- a third of the bytes, the same keys in the same registers
+    const unsigned nvec0 = kS3 ? (unsigned)a.x_s3 / 4u : 0u;
 #pragma unroll
     for (int u0 = 0; u0 < U; u0 += B) {
-      float4 v[B][3];
+      float4 v[B][kS3 ? 1 : 3];
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         if (u0 + b < U) {
           const unsigned jt = (unsigned)tid + (unsigned)(u0 + b) * kThreads;
+          if constexpr (kS3) {
+            v[b][0] = row4[min(jt, nvec0 - 1u)];
+          } else {
 #pragma unroll
-          for (int t = 0; t < 3; ++t) v[b][t] = row4[min(3u * jt + (unsigned)t, nvec - 1u)];
+            for (int t = 0; t < 3; ++t) v[b][t] = row4[min(3u * jt + (unsigned)t, nvec - 1u)];
+          }
         }
       }
 #pragma unroll
@@ -1822,7 +1889,8 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
         if (u0 + b < U) {
           const unsigned jt = (unsigned)tid + (unsigned)(u0 + b) * kThreads;
           const unsigned e0 = 12u * jt;
-          float xs[4] = {v[b][0].x, v[b][0].w, v[b][1].z, v[b][2].y};
+          float xs[4] = {v[b][0].x, kS3 ? v[b][0].y : v[b][0].w, kS3 ? v[b][0].z : v[b][kS3 ? 0 : 1].z,
+                         kS3 ? v[b][0].w : v[b][kS3 ? 0 : 2].y};
           if (affine) {
             // channel of element e0 (e0 / HW via a reciprocal, corrected); the other three sub-sampled elements
             // are at most one channel boundary further each (HW >= 4).  Scale / shift come from the LDS copy.
@@ -2085,6 +2153,7 @@ __global__ __launch_bounds__(T) void aq_greedy2_kernel(FusedArgs a) {
   }
 }
 
+#if !LSQ_FUSED_S3
 template <int T>
 int launch_greedy(const FusedArgs& a, int vec, hipStream_t st) {
   if (vec == 4) hipLaunchKernelGGL((aq_greedy2_kernel<T, 4>), dim3(a.N), dim3(T), 0, st, a);
@@ -2108,6 +2177,7 @@ int launch_forced(const FusedArgs& a, int vec, hipStream_t st) {
   else hipLaunchKernelGGL((aq_forced_kernel<T, 1>), grid, dim3(T), 0, st, a);
   return (int)hipGetLastError();
 }
+#endif
 
 template <int T, int U>
 int launch(const FusedArgs& a, int vec, hipStream_t st) {
@@ -2123,9 +2193,11 @@ int launch(const FusedArgs& a, int vec, hipStream_t st) {
     else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2, true>), dim3(a.N), dim3(T), 0, st, a);
     else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1, true>), dim3(a.N), dim3(T), 0, st, a);
   } else {
+#if !LSQ_FUSED_S3
     if (vec == 4) hipLaunchKernelGGL((aq_fused_kernel<T, U, 4, false>), dim3(a.N), dim3(T), 0, st, a);
     else if (vec == 2) hipLaunchKernelGGL((aq_fused_kernel<T, U, 2, false>), dim3(a.N), dim3(T), 0, st, a);
     else hipLaunchKernelGGL((aq_fused_kernel<T, U, 1, false>), dim3(a.N), dim3(T), 0, st, a);
+#endif
   }
 #endif
   return (int)hipGetLastError();
@@ -2133,8 +2205,19 @@ int launch(const FusedArgs& a, int vec, hipStream_t st) {
 
 }  // namespace
 
+#if LSQ_FUSED_S3
+int fused_act_quant_s3(const FusedArgs& a_in, hipStream_t st) {
+  FusedArgs a = a_in;
+  // three-stream rows: the solving kernels only (given scales and gf-2 read the row once as it is); H W = 3 h + 1, streams
+  // of S floats (a multiple of 4, at least ceil(M / 3) + 8: pass 2's last items read a few floats past a stream's end)
+  if (a.forced || a.greedy || a.x_s3 <= 0 || a.x_s3 % 4 || ((long long)a.H * a.W) % 3 != 1 ||
+      a.x_s3 < (a.row_elems + 2) / 3 + 8 || (a.cg & 63) != 0 || a.C > kBnCap)
+    return kFusedNotEligible;
+#else
 int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
   FusedArgs a = a_in;
+  if (a.x_s3) return kFusedNotEligible;
+#endif
   const long long HW = (long long)a.H * a.W;
   const long long M = a.row_elems;
   // windowed level-1 histogram of the solve (solve_windowed): under a symmetric clamp every key is at most key(alpha), so the
@@ -2157,21 +2240,26 @@ int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
   // address pass of the load path) or many rounds, two for the 1..4 rounds in between (56 x 56 x 64: 784 four-pixel
   // items on 512 lanes are two rounds with the second half empty)
   int vec = 1;
-  const long long items4 = (long long)a.Gt * (HW / 4);
-  if (HW % 4 == 0 && (items4 <= T || items4 >= 4 * T)) vec = 4;
-  else if (HW % 2 == 0) vec = 2;
+  const long long items4 = kS3 ? (long long)a.Gt * 3 * ((HW + 11) / 12) : (long long)a.Gt * (HW / 4);
+  if ((kS3 || HW % 4 == 0) && (items4 <= T || items4 >= 4 * T)) vec = 4;
+  else if (kS3 || HW % 2 == 0) vec = 2;
+  if (kS3 && (long long)a.Gt * 3 * ((HW + 2) / 3) <= T) vec = 1;      // (the 7 x 7 rows: one pixel per lane, as the NCHW kernels)
 #ifdef LSQ_TUNE
   if (const char* e = getenv("LSQ_FUSED_VEC")) {
     const int v = atoi(e);
     if ((v == 4 || v == 2 || v == 1) && HW % v == 0) vec = v;
   }
 #endif
+#if !LSQ_FUSED_S3
   if (a.forced) {
     if (a.N > 65535) return kFusedNotEligible;       // (grid y)
     // no rounds to balance here: the widest loads the image allows
     return launch_forced<T>(a, HW % 4 == 0 ? 4 : (HW % 2 == 0 ? 2 : 1), st);
   }
   if (a.greedy) return launch_greedy<T>(a, vec, st);
+#else
+  if (!a.win_sh) return kFusedNotEligible;           // (rows under a symmetric clamp: the windowed kernels, with their fall-back)
+#endif
   const long long ntrip = (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
 #ifdef LSQ_DEV_U
@@ -2185,7 +2273,7 @@ int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
 #endif
 }
 
-#ifdef LSQ_PHASE_CLOCKS
+#if defined(LSQ_PHASE_CLOCKS) && !LSQ_FUSED_S3
 extern "C" int lsq_debug_read_fused_times(long long* host16384) {
   return (int)hipMemcpyFromSymbol(host16384, HIP_SYMBOL(g_fused_times), 16384 * sizeof(long long));
 }

@@ -1829,11 +1829,12 @@ extern "C" int64_t lsq_act_plane_words(const lsq_conv_geom* g) {
 extern "C" int64_t lsq_solver_workspace_bytes(int64_t rows) { return rows > 0 ? rows * kWsRow : -1; }
 extern "C" int64_t lsq_sweep_workspace_bytes(int64_t rows) { return rows > 0 ? rows * kSplitRow : -1; }
 
-extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
-                             float clamp_alpha, const float* pre_scale, const float* pre_shift,
-                             const float* forced, uint64_t* planes, float* scales,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+static int act_quant_impl(const float* x, int x_layout, const lsq_conv_geom* g, int scheme, int k, int skip,
+                          float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                          const float* forced, uint64_t* planes, float* scales,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !planes || !scales) return LSQ_E_NULL;
+  if (x_layout != LSQ_LAYOUT_NCHW && x_layout != LSQ_LAYOUT_SPLIT3) return LSQ_E_SCHEME;
   if (int e = check_geom(g)) return e;
   if (skip < 1) return LSQ_E_SHAPE;
   if (k < 1 || k > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
@@ -1891,14 +1892,39 @@ extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme,
     f.forced = forced2 ? forced : nullptr;
     f.trace = g_solver_trace.load(std::memory_order_relaxed);
     f.greedy = (gf2 && !forced) ? 1 : 0;
+    if (x_layout == LSQ_LAYOUT_SPLIT3) {
+      // three-stream rows (include/lsq_hip.h): the single-launch solving kernels read them, nothing else does
+      const int64_t S = lsq_split3_stream_floats(g->C, g->H, g->W);
+      if (S <= 0 || !solver || ((uintptr_t)x % 16) != 0) return LSQ_E_UNSUPPORTED;
+      f.x_s3 = (int)S;
+      const int e = fused_act_quant_s3(f, st);
+      return e == kFusedNotEligible ? LSQ_E_UNSUPPORTED : e;
+    }
     const int e = fused_act_quant(f, st);
     if (e != kFusedNotEligible) return e;
   }
+  if (x_layout != LSQ_LAYOUT_NCHW) return LSQ_E_UNSUPPORTED;
   // widest loads the image allows; rows with fewer items than threads split the 64 channels of an item over lanes
   // (run<VEC>), so small images take 16-byte loads too
   if (HW % 4 == 0 && al16 && (long long)a.Gt * (HW / 4) >= 16) return run<4>(a, st);
   if (HW % 2 == 0 && al8 && (long long)a.Gt * (HW / 2) >= 16) return run<2>(a, st);
   return run<1>(a, st);
+}
+
+extern "C" int lsq_act_quant(const float* x, const lsq_conv_geom* g, int scheme, int k, int skip,
+                             float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                             const float* forced, uint64_t* planes, float* scales,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  return act_quant_impl(x, LSQ_LAYOUT_NCHW, g, scheme, k, skip, clamp_alpha, pre_scale, pre_shift, forced, planes, scales, workspace,
+                        workspace_bytes, stream);
+}
+
+extern "C" int lsq_act_quant_layout(const float* x, int x_layout, const lsq_conv_geom* g, int scheme, int k, int skip,
+                                    float clamp_alpha, const float* pre_scale, const float* pre_shift,
+                                    const float* forced, uint64_t* planes, float* scales,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return act_quant_impl(x, x_layout, g, scheme, k, skip, clamp_alpha, pre_scale, pre_shift, forced, planes, scales, workspace,
+                        workspace_bytes, stream);
 }
 
 extern "C" int lsq_solve_rows(const float* rows, int64_t R, int64_t M, int skip, int ternary,

@@ -27,6 +27,9 @@ struct ConvArgs {
   int res_stream;                      // the residual operand is read with the non-temporal hint: it and the output together exceed the
                                        // Infinity Cache and this is its last use (set by the entry point, kStreamBytes)
   int dbg_no_corr;                     // tuning builds only
+  // ---- three-stream rows (LSQ_LAYOUT_SPLIT3, include/lsq_hip.h): 0 = NCHW, else S = floats per stream of the tensor's rows
+  int y_s3;                            // layout of y (and of the partial sums read back with `accumulate`)
+  int res_s3;                          // layout of res_pre / res_post (both)
   // ---- chained 1-bit layers (lsq_xnor_conv2d_chain): the NEXT layer's ls-1 quantizer in this layer's epilogue, and this
   // layer's activation scale from the exact row sum the PREVIOUS layer's epilogue left
   const long long* xunits;             // [N] or null: row sum of |clamp(x)| in units of 2^e; xscale = float(units * xunit / xM)
@@ -49,6 +52,7 @@ struct ConvArgs {
 constexpr long long kInfinityCacheBytes = 256ll << 20;
 
 constexpr int kXnorMfmaNotEligible = 1;
+constexpr int kXnorMfmaNoLayout = 2;     // a three-stream operand on a geometry without such a kernel: LSQ_E_UNSUPPORTED
 // One launch (one weight plane x kx <= 2 activation planes) on the matrix cores; kXnorMfmaNotEligible when the
 // geometry is not covered (the caller then takes the popcount kernel), else hipGetLastError().
 int xnor_conv_mfma(const ConvArgs& a, int kx, int groups, hipStream_t st);

@@ -254,7 +254,8 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
                             const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
                             const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
                             const float* res_post, float* y, void* stream,
-                            const int64_t* x_units, float x_alpha, const lsq_next_ls1* next) {
+                            const int64_t* x_units, float x_alpha, const lsq_next_ls1* next,
+                            int y_layout = LSQ_LAYOUT_NCHW, int res_layout = LSQ_LAYOUT_NCHW) {
   if (!xplanes || (!xscales && !x_units) || !wbits || !wsum || !wscales || !y) return LSQ_E_NULL;
   if (int e = check_geom(g)) return e;
   if (kx < 1 || kx > LSQ_MAX_PLANES || kw_planes < 1 || kw_planes > LSQ_MAX_PLANES) return LSQ_E_SCHEME;
@@ -284,6 +285,17 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
   a.res_pre = res_pre;
   a.res_post = res_post;
   a.res_stream = 2ll * 4 * (long long)g->N * g->O * Ho * Wo > kInfinityCacheBytes;
+  if ((y_layout != LSQ_LAYOUT_NCHW && y_layout != LSQ_LAYOUT_SPLIT3) || (res_layout != LSQ_LAYOUT_NCHW && res_layout != LSQ_LAYOUT_SPLIT3))
+    return LSQ_E_SCHEME;
+  if (!res_pre && !res_post) res_layout = LSQ_LAYOUT_NCHW;
+  const bool layouts = y_layout != LSQ_LAYOUT_NCHW || res_layout != LSQ_LAYOUT_NCHW;
+  if (layouts) {
+    // three-stream rows (include/lsq_hip.h): the integer-MFMA kernel only
+    const int64_t S = lsq_split3_stream_floats(g->O, Ho, Wo);
+    if (S <= 0 || 3 * S * g->N >= (1ll << 31) || g_force_popcount.load(std::memory_order_relaxed) || x_units || next) return LSQ_E_UNSUPPORTED;
+    a.y_s3 = y_layout == LSQ_LAYOUT_SPLIT3 ? (int)S : 0;
+    a.res_s3 = res_layout == LSQ_LAYOUT_SPLIT3 ? (int)S : 0;
+  }
   const bool chained = x_units != nullptr || next != nullptr;
   if (chained) {
     // chained 1-bit layers run on the integer-MFMA kernel only (3x3, C in {64, 128, 256, 512}); one activation plane
@@ -329,7 +341,7 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
       a.accumulate = first ? 0 : 1;
       a.final_pass = (q == kw_planes - 1 && p0 + np >= kx) ? 1 : 0;
       int e = (g_force_popcount.load(std::memory_order_relaxed) && !chained) ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
-      if (e == kXnorMfmaNotEligible && chained) return LSQ_E_UNSUPPORTED;
+      if (e == kXnorMfmaNoLayout || (e == kXnorMfmaNotEligible && (chained || layouts))) return LSQ_E_UNSUPPORTED;
       if (e == kXnorMfmaNotEligible) e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
       if (e) return e;
       first = false;
@@ -345,6 +357,38 @@ extern "C" int lsq_xnor_conv2d(const uint64_t* xplanes, int kx, const float* xsc
                                float* y, void* stream) {
   return xnor_conv2d_impl(xplanes, kx, xscales, wbits, wsum, kw_planes, wscales, bias, g, relu, act_slope, res_pre, res_post, y,
                           stream, nullptr, -1.f, nullptr);
+}
+
+extern "C" int lsq_xnor_conv2d_layout(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
+                                      const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
+                                      const lsq_conv_geom* g, int relu, const float* act_slope, const float* res_pre,
+                                      const float* res_post, int res_layout, float* y, int y_layout, void* stream) {
+  return xnor_conv2d_impl(xplanes, kx, xscales, wbits, wsum, kw_planes, wscales, bias, g, relu, act_slope, res_pre, res_post, y,
+                          stream, nullptr, -1.f, nullptr, y_layout, res_layout);
+}
+
+extern "C" int64_t lsq_split3_stream_floats(int64_t C, int64_t H, int64_t W) {
+  if (C <= 0 || H <= 0 || W <= 0 || (H * W) % 3 != 1) return -1;
+  const int64_t n0 = (C * H * W + 2) / 3;
+  return (n0 + 8 + 31) / 32 * 32;
+}
+
+extern "C" int lsq_layout_support(const lsq_conv_geom* g, int scheme, int kx) {
+  if (check_geom(g)) return 0;
+  int mask = 0;
+  const int cg = g->C / g->groups;
+  // bit 0: the single-launch solving quantizer (lsq_act_fused.hip) on three-stream rows
+  const long long M = (long long)g->C * g->H * g->W;
+  if ((scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && lsq_split3_stream_floats(g->C, g->H, g->W) > 0 && cg % 64 == 0 &&
+      g->C <= 1024 && M % 4 == 0 && (long long)g->H * g->W >= 4 && ((M / 4 + 2) / 3 + 511) / 512 <= 33)
+    mask |= 1;
+  // bits 1, 2: the integer-MFMA convolution's three-stream kernels (lsq_xnor_mfma.hip)
+  const int Ho = out_h(g), Wo = out_w(g);
+  if (g->groups == 1 && g->KH == 3 && g->KW == 3 && g->dil_w == 1 && g->O % 32 == 0 && kx == 2 && (cg == 64 || cg == 128) &&
+      Ho > 0 && Wo > 0 && lsq_split3_stream_floats(g->O, Ho, Wo) > 0 && 3 * lsq_split3_stream_floats(g->O, Ho, Wo) * g->N < (1ll << 30) &&
+      !g_force_popcount.load(std::memory_order_relaxed))
+    mask |= 2 | 4;
+  return mask;
 }
 
 extern "C" int lsq_xnor_conv2d_chain(const uint64_t* xplanes, const float* xscales, const int64_t* x_units, float x_alpha,

@@ -42,8 +42,19 @@ constexpr unsigned kM0 = 0x01010101u;
 // NWAVES: waves per workgroup, all on the same 32 out-channels: 8 -- one workgroup per CU, two waves per SIMD -- for 256 and
 // 512 channels (the fragments of 512 channels fill the LDS of a CU; at 256 channels one workgroup of 8 waves expands
 // the weights and builds the tables ONCE where two workgroups of 4 did it twice: 59-60 -> 55-56 us per 14 x 14 layer, round 4).
-template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN>
+//
+// S3: kernels that read / write fp32 tensors in the THREE-STREAM ROW layout (include/lsq_hip.h, LSQ_LAYOUT_SPLIT3): element e
+// of a sample's row (e = c * HoWo + pixel) lives at (e % 3) * S + e / 3, so that the sub-sample e % 3 == 0 the next layer's
+// scale solve reads (quantization.py:63, skip = 3) is ONE contiguous third of the row instead of every third float of all of
+// it.  HoWo % 3 == 1 (every ResNet shape), hence e % 3 = (c + pixel) % 3 and e / 3 = c * h3 + (c + pixel) / 3, h3 = HoWo / 3.
+// When the OUTPUT has that layout a tile is 32 pixels at stride 3 -- flat pixel 96 (tile / 3) + tile % 3 + 3 lane --, so the
+// 32 lanes of a channel's store are 32 consecutive floats of one stream, as coalesced as the NCHW store; the bit-plane reads
+// of such a tile are the 32 lanes' 24-byte windows back to back (no overlap inside a tile; the three tiles of a group of 96
+// pixels read the same lines shifted by one word).  Residual operands may have either layout.
+template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN, bool YS3, bool RS3>
 __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
+  constexpr bool S3 = YS3 || RS3;                // (which operands have the three-stream layout is fixed per instantiation:
+                                                 //  runtime selects between two sets of sixteen channel offsets cost scalar registers)
   constexpr int NT = 64 * NWAVES;
   constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (word, tap, half of the dword's bits)
   constexpr int NW = TAPS * KX;                  // activation dwords per lane and group (= one channel word of a tile)
@@ -61,12 +72,15 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 
   // ---- tile bookkeeping (before the tables: the first loads go out early) --------------------------------------
   const unsigned total = (unsigned)(a.N * a.Ho * a.Wo);
-  const int ntiles = (int)((total + 31u) >> 5);
   const int HoWo = a.Ho * a.Wo;
+  constexpr bool map3 = YS3;                     // tiles of 32 pixels at stride 3: the output is a three-stream tensor
+  const int ntiles = map3 ? 3 * (int)((total + 95u) / 96u) : (int)((total + 31u) >> 5);
+  const unsigned s3_S = (unsigned)(a.y_s3 ? a.y_s3 : a.res_s3), s3_h = (unsigned)HoWo / 3u;    // floats per stream; HoWo = 3 h + 1
   const unsigned* __restrict__ xd = reinterpret_cast<const unsigned*>(a.xplanes);
   const unsigned plane_stride = 2u * (unsigned)a.xplane_words;
   const int tstride = gridDim.x * NWAVES;
   // a wave's pixel index advances by the same amount from tile to tile: (n, ho, wo) follow with adds and carries
+  // (stride-3 tiles: tstride is a multiple of 3 -- the launcher sees to it --, so tile % 3 stays and the step is the same)
   const unsigned dstep = 32u * (unsigned)tstride;
   const int d_n = (int)(dstep / (unsigned)HoWo);
   const int d_r = (int)(dstep - (unsigned)d_n * (unsigned)HoWo);
@@ -115,13 +129,45 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       }
   };
 
+  // Element offset of (sample, out-channel o0 + ob + k, the lane's pixel) = v[k % 3] + koff(k), koff uniform: NCHW
+  // v[.] = ((n O + o0 + ob) HoWo + pixel), koff = k HoWo; three streams: with u = o0 + ob + pixel, channel k sits in stream
+  // (u + k) % 3 at rank (o0 + ob + k) h + (u + k) / 3, and (u + k) / 3 = k / 3 + (u + k % 3) / 3 -- so v[m] = n * 3 S +
+  // ((u + m) % 3) S + (u + m) / 3 + (o0 + ob) h and koff = k h + k / 3.
+  struct Lay {
+    unsigned v[S3 ? 3 : 1];
+  };
+  auto lay_of = [&](unsigned pix, int ln, bool s3, Lay& L) {
+    if constexpr (S3) {
+      if (s3) {
+        const unsigned u0 = (unsigned)(o0 + ob) + pix;
+        const unsigned q0 = __umulhi(u0, 0xAAAAAAABu) >> 1, r0 = u0 - 3u * q0;
+        const unsigned base = (unsigned)ln * 3u * s3_S + (unsigned)(o0 + ob) * s3_h + q0;
+        L.v[0] = base + r0 * s3_S;
+        L.v[1] = base + (r0 == 2u ? 1u : (r0 + 1u) * s3_S);
+        L.v[2] = base + (r0 == 0u ? 2u * s3_S : (r0 == 1u ? 1u : s3_S + 1u));
+        return;
+      }
+    }
+    const unsigned yoff = (unsigned)((ln * a.O + o0 + ob) * HoWo) + pix;
+#pragma unroll
+    for (int m = 0; m < (S3 ? 3 : 1); ++m) L.v[m] = yoff;
+  };
+  constexpr bool y_s3 = YS3, r_s3 = RS3;
+  // (uniform) element offset of register i's channel k = (i & 3) + 8 (i >> 2) on top of Lay::v[k % 3]
+  auto koff = [&](int i, bool s3) -> long long {
+    const int k = (i & 3) + 8 * (i >> 2);
+    return (S3 && s3) ? (long long)k * s3_h + k / 3 : (long long)k * HoWo;
+  };
+  auto kv = [&](const Lay& L, int i) -> unsigned { return L.v[S3 ? ((i & 3) + 8 * (i >> 2)) % 3 : 0]; };
+
   // wave-major numbering: when the tiles do not divide evenly, the waves with one tile more sit in different
   // workgroups (on different SIMDs) instead of filling one
   int tile = wid * gridDim.x + blockIdx.x;
   const bool have_tile = tile < ntiles;
   Pix cur;
   {
-    const unsigned p = (unsigned)tile * 32u + (unsigned)col;
+    const unsigned p = map3 ? (unsigned)(tile / 3) * 96u + (unsigned)(tile % 3) + 3u * (unsigned)col
+                            : (unsigned)tile * 32u + (unsigned)col;
     cur.n = (int)(p / (unsigned)HoWo);
     const int r = (int)(p - (unsigned)cur.n * (unsigned)HoWo);
     cur.ho = (int)((unsigned)r / (unsigned)a.Wo);
@@ -253,7 +299,13 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     // its full latency -- that, not the MFMA rate, set the pace of the first version.
     const int ln = cur.n < a.N ? cur.n : 0;
     // 32-bit element offsets from uniform bases (the entry point admits outputs below 2^30 elements)
-    const unsigned yoff = (unsigned)((ln * a.O + o0 + ob) * HoWo + cur.ho * a.Wo + cur.wo);
+    // (three-stream kernels: the offsets are worked out where they are used -- here for the loads, again in front of the
+    //  stores from an opaque copy of the pixel -- instead of living through the MFMA loop: the 128-channel kernel sits at
+    //  its 168-register budget)
+    Lay ly, lr;
+    unsigned pixv = (unsigned)(cur.ho * a.Wo + cur.wo);
+    lay_of(pixv, ln, y_s3, ly);
+    lay_of(pixv, ln, r_s3, lr);
     float xs[KX], rv[16], basev[16];
 #pragma unroll
     for (int p = 0; p < KX; ++p) xs[p] = (!CHAIN || a.xscales) ? a.xscales[p * a.N + ln] * 0.03125f : 0.f;
@@ -263,10 +315,10 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
       if (a.res_stream) {           // (uniform) last use of a tensor that does not fit the Infinity Cache next to the output: lsq_xnor_conv.h
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = __builtin_nontemporal_load(rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo + yoff);
+        for (int i = 0; i < 16; ++i) rv[i] = __builtin_nontemporal_load(rsrc + koff(i, r_s3) + kv(lr, i));
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rv[i] = (rsrc + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+        for (int i = 0; i < 16; ++i) rv[i] = (rsrc + koff(i, r_s3))[kv(lr, i)];
       }
     } else {
 #pragma unroll
@@ -274,7 +326,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     }
     if (acc_in) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) basev[i] = (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+      for (int i = 0; i < 16; ++i) basev[i] = (a.y + koff(i, y_s3))[kv(ly, i)];
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) basev[i] = s_bias[ob + (i & 3) + 8 * (i >> 2)];
@@ -360,6 +412,11 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 #pragma unroll
       for (int i = 0; i < 16; ++i) nqv[i] = 0.f;
     }
+    if constexpr (S3) {
+      asm volatile("" : "+v"(pixv));
+      lay_of(pixv, ln, y_s3, ly);
+      if (want_post && want_pre) lay_of(pixv, ln, r_s3, lr);
+    }
     if (cur.n < a.N) {                           // (false only for the lanes past the last pixel)
       // float(acc) = 32 * (b * s) exactly (|.| < 2^18) and xs / 32 is exact, so (xs / 32) * float(acc) is the very
       // product xs * float(b * s) of the popcount kernel
@@ -404,14 +461,14 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       }
       if (want_post && want_pre) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) outv[i] += (a.res_post + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff];
+        for (int i = 0; i < 16; ++i) outv[i] += (a.res_post + koff(i, r_s3))[kv(lr, i)];
       }
 #ifdef LSQ_XNOR_CLOCKS
       asm volatile("" :: "v"(outv[0]), "v"(outv[15]));
       XCLK();
 #endif
 #pragma unroll
-      for (int i = 0; i < 16; ++i) (a.y + (long long)((i & 3) + 8 * (i >> 2)) * HoWo)[yoff] = outv[i];
+      for (int i = 0; i < 16; ++i) (a.y + koff(i, y_s3))[kv(ly, i)] = outv[i];
       if constexpr (CHAIN) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) nqv[i] = outv[i];
@@ -498,10 +555,29 @@ int launch(const ConvArgs& a, hipStream_t st) {
   long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
   if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
+  if (a.y_s3 || a.res_s3) {
+    // three-stream tensors: the two-plane kernels of 64 / 128 channels (the 56 x 56 and 28 x 28 layers of the network, whose
+    // rows are the long ones); a three-stream OUTPUT means tiles at pixel stride 3, whose bookkeeping wants the tile stride
+    // of a wave to be a multiple of 3
+    if constexpr (KX == 2 && GG <= 2) {
+      if (a.y_s3) {
+        const long long nt3 = 3 * ((total + 95) / 96);
+        if (gx * NWAVES > nt3) gx = (nt3 + NWAVES - 1) / NWAVES;
+        if ((gx * NWAVES) % 3) gx = gx >= 3 ? gx - gx % 3 : 3;
+      }
+      const dim3 grid((unsigned)gx, (unsigned)n_ot), block(64 * NWAVES);
+      if (a.y_s3 && a.res_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, true>), grid, block, 0, st, a);
+      else if (a.y_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, false>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, true>), grid, block, 0, st, a);
+      return (int)hipGetLastError();
+    } else {
+      return kXnorMfmaNoLayout;
+    }
+  }
   if (KX == 1 && (a.xunits || a.nq_planes32))
-    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   else
-    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
 }
 

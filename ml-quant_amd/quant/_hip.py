@@ -19,7 +19,8 @@ _LIB_PATH = os.environ.get('LSQ_HIP_LIB') or os.path.join(   # (LSQ_HIP_LIB: dev
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 10
+ABI_VERSION = 11
+LAYOUT_NCHW, LAYOUT_SPLIT3 = 0, 1
 SCHEME_LS1, SCHEME_LS2, SCHEME_LST, SCHEME_GF = 1, 2, 3, 4
 MAX_PLANES = 8
 MAX_XNOR_KERNEL = 8          # lsq_xnor_conv2d: KH, KW <= 8
@@ -68,6 +69,14 @@ def _declare(lib):
     lib.lsq_weight_plane_words.argtypes = [gp]
     lib.lsq_act_quant.restype = i32
     lib.lsq_act_quant.argtypes = [vp, gp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.lsq_act_quant_layout.restype = i32
+    lib.lsq_act_quant_layout.argtypes = [vp, i32, gp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.lsq_split3_stream_floats.restype = i64
+    lib.lsq_split3_stream_floats.argtypes = [i64, i64, i64]
+    lib.lsq_layout_support.restype = i32
+    lib.lsq_layout_support.argtypes = [gp, i32, i32]
+    lib.lsq_xnor_conv2d_layout.restype = i32
+    lib.lsq_xnor_conv2d_layout.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, gp, i32, vp, vp, vp, i32, vp, i32, vp]
     lib.lsq_solver_workspace_bytes.restype = i64
     lib.lsq_solver_workspace_bytes.argtypes = [i64]
     lib.lsq_sweep_workspace_bytes.restype = i64
@@ -299,21 +308,39 @@ def sweep_workspace(rows: int, device) -> torch.Tensor:
     return buf
 
 
+_layout_memo = {}
+
+
+def layout_support(geom: ConvGeom, scheme: int, kx: int) -> int:
+    """Bit mask of the operands of a call with this geometry that may be three-stream tensors (lsq_layout_support)."""
+    key = (geom.key(), scheme, kx)
+    hit = _layout_memo.get(key)
+    if hit is None:
+        if len(_layout_memo) > 256:
+            _layout_memo.clear()
+        hit = _layout_memo[key] = int(lib().lsq_layout_support(ctypes.byref(geom), scheme, kx))
+    return hit
+
+
 def act_quant(x: torch.Tensor, geom: ConvGeom, scheme: int, k: int, skip: int, alpha: float,
               planes: torch.Tensor, scales: torch.Tensor, forced: Optional[torch.Tensor] = None,
-              pre: Optional[tuple] = None) -> None:
-    """pre = (scale[C], shift[C]) folds an eval-mode batch norm into the read."""
-    x = _f32c(x)
+              pre: Optional[tuple] = None, x_layout: int = LAYOUT_NCHW) -> None:
+    """pre = (scale[C], shift[C]) folds an eval-mode batch norm into the read.  ``x_layout`` = LAYOUT_SPLIT3: ``x`` is the
+    [N, 3 S] buffer of a three-stream tensor (quant.binary.layouts)."""
+    if x_layout == LAYOUT_NCHW:
+        x = _f32c(x)
+    elif x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError('a three-stream operand is passed as its contiguous fp32 [N, 3 S] buffer')
     ws = None
     if forced is None:
         ws = solver_workspace(geom.N, x.device) if scheme in (SCHEME_LS2, SCHEME_LST) else sweep_workspace(geom.N, x.device)
     m = geom.C * geom.H * geom.W
     # (accounting -- x read once + k bit planes written -- only when a benchmark asked for it: the record costs microseconds)
     with _on(x), (_Timed('lsq_act_quant', geom.N * (4 * m + k * m // 8), 0, f'C{geom.C}_H{geom.H}') if _timing is not None else _UNTIMED):
-        check(lib().lsq_act_quant(x.data_ptr(), ctypes.byref(geom), scheme, k, skip, float(alpha),
-                                  None if pre is None else pre[0].data_ptr(), None if pre is None else pre[1].data_ptr(),
-                                  ptr(forced), planes.data_ptr(), scales.data_ptr(), ptr(ws),
-                                  0 if ws is None else ws.numel(), stream_ptr(x.device)), 'lsq_act_quant')
+        check(lib().lsq_act_quant_layout(x.data_ptr(), x_layout, ctypes.byref(geom), scheme, k, skip, float(alpha),
+                                         None if pre is None else pre[0].data_ptr(), None if pre is None else pre[1].data_ptr(),
+                                         ptr(forced), planes.data_ptr(), scales.data_ptr(), ptr(ws),
+                                         0 if ws is None else ws.numel(), stream_ptr(x.device)), 'lsq_act_quant')
 
 
 def solve_rows(rows: torch.Tensor, skip: int, ternary: bool, alpha: float = -1.0):
@@ -371,26 +398,32 @@ def _act(relu: bool, prelu: Optional[torch.Tensor], out_channels: int):
 def xnor_conv2d(planes: torch.Tensor, kx: int, xscales: torch.Tensor, wbits: torch.Tensor, wsum: torch.Tensor,
                 wscales: torch.Tensor, bias: Optional[torch.Tensor], geom: ConvGeom, y: torch.Tensor,
                 relu: bool = False, res_pre: Optional[torch.Tensor] = None,
-                res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None) -> None:
+                res_post: Optional[torch.Tensor] = None, prelu: Optional[torch.Tensor] = None,
+                y_layout: int = LAYOUT_NCHW, res_layout: int = LAYOUT_NCHW) -> None:
     """y = act(conv + bias + res_pre) + res_post, act = ReLU (``relu``), PReLU (``prelu`` = its weight) or identity
-    (the fused block epilogue is optional)."""
+    (the fused block epilogue is optional).  ``y_layout`` / ``res_layout`` = LAYOUT_SPLIT3: ``y`` / the residuals are the
+    [N, 3 S] buffers of three-stream tensors (quant.binary.layouts); ``y.numel()`` below then counts the padding too -- the
+    accounting uses the geometry."""
     act, slope = _act(relu, prelu, geom.O)
     m = geom.C * geom.H * geom.W
-    macs = y.numel() * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
+    ho_, wo_ = out_hw(geom)
+    ynum = geom.N * geom.O * ho_ * wo_
+    macs = ynum * (geom.C // geom.groups) * geom.KH * geom.KW * kx * wscales.shape[0]
     nres = (res_pre is not None) + (res_post is not None)
-    if y.numel() >= XNOR_MFMA_MAX_OUTPUTS and (geom.KH, geom.KW, geom.groups, geom.dil_h, geom.dil_w) == (3, 3, 1, 1, 1) \
+    if ynum >= XNOR_MFMA_MAX_OUTPUTS and (geom.KH, geom.KW, geom.groups, geom.dil_h, geom.dil_w) == (3, 3, 1, 1, 1) \
             and geom.C in (64, 128, 256, 512) and geom.O % 32 == 0 and 'outputs' not in _xnor_limit_warned:
         # (csrc/lsq_xnor_mfma.hip indexes its output with 32 bits: a call this large is served by the popcount kernel -- same
         #  bits, about half the speed.  Said once, not silently.)
         _xnor_limit_warned.add('outputs')
-        warnings.warn(f'lsq_xnor_conv2d: {y.numel()} outputs (2^30 or more): this call runs on the popcount kernel instead of the '
+        warnings.warn(f'lsq_xnor_conv2d: {ynum} outputs (2^30 or more): this call runs on the popcount kernel instead of the '
                       'int8 matrix-core kernel (same result, about half the speed); split the batch to stay below 2^30 outputs')
     # algorithmic bytes: planes read + fp32 output written + every residual operand of the fused epilogue read
-    with _on(y), (_Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * y.numel() * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
-                         geom.N * kx * m // 8 + 4 * y.numel()) if _timing is not None else _UNTIMED):
-        check(lib().lsq_xnor_conv2d(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
-                                    wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
-                                    ptr(res_pre), ptr(res_post), y.data_ptr(), stream_ptr(y.device)), 'lsq_xnor_conv2d')
+    with _on(y), (_Timed('lsq_xnor_conv2d', geom.N * kx * m // 8 + 4 * ynum * (1 + nres), macs, f'C{geom.C}_H{geom.H}_s{geom.stride_h}',
+                         geom.N * kx * m // 8 + 4 * ynum) if _timing is not None else _UNTIMED):
+        check(lib().lsq_xnor_conv2d_layout(planes.data_ptr(), kx, xscales.data_ptr(), wbits.data_ptr(), wsum.data_ptr(),
+                                           wscales.shape[0], wscales.data_ptr(), ptr(bias), ctypes.byref(geom), act, ptr(slope),
+                                           ptr(res_pre), ptr(res_post), res_layout, y.data_ptr(), y_layout,
+                                           stream_ptr(y.device)), 'lsq_xnor_conv2d')
 
 
 E_UNSUPPORTED = -6

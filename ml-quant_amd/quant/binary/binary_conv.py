@@ -248,7 +248,7 @@ class QuantConv2d(nn.Conv2d):
             return None
         if n * self.out_channels * ho * wo > chain.MAX_ELEMENTS:    # (large layers: the separate HBM-bound sweep is cheaper)
             return None
-        bn, conv = next_q
+        bn, conv = next_q[0], next_q[1]
         if not isinstance(conv, QuantConv2d) or conv.x_quant != 'ls-1' or conv.training or conv.w_quant == 'fp':
             return None
         if conv.in_channels != self.out_channels or conv.groups != 1 or isinstance(conv.padding, str) or conv.padding_mode != 'zeros':
@@ -276,7 +276,41 @@ class QuantConv2d(nn.Conv2d):
         keep = (planes, units, pre)
         return nxt, chain.PreQuant(conv, bn, planes, units, (n, self.out_channels, ho, wo), _hip.stream_ptr(device)), keep
 
-    def _act_planes(self, x, geom, k, n, pre, xq, _hip):
+    def _reads_split3(self, geom, n: int, _hip) -> bool:
+        """Can this call's quantizer read a three-stream input (quant.binary.layouts)?  The solving ls-2 / ls-T kernels under a
+        symmetric clamp, sub-sampling stride 3, no given scales."""
+        if self.x_quant not in ('ls-2', 'ls-T') or self.act_skip != 3 or self._alpha() <= 0:
+            return False
+        if self.x_approximate.eval_scales(n) is not None:
+            return False
+        return bool(_hip.layout_support(geom, self.x_approximate.hip_scheme, 2) & 1)
+
+    def _split3_output(self, next_q, geom, n: int, ho: int, wo: int, device, _hip) -> bool:
+        """Should this call leave its output as a three-stream tensor?  Only when every consumer is known to read one:
+        ``next_q = (bn, conv[, shortcut])`` -- the quantizer of ``conv`` (the solve then reads 4/3 of the row instead of twice
+        all of it), ``conv``'s epilogue (the tensor as a residual operand) and, if given, the projection ``shortcut`` of
+        ``conv``'s block."""
+        from quant.binary import layouts
+        if next_q is None or not layouts.ENABLED or self.x_quant not in ('ls-2', 'ls-T'):
+            return False
+        if not (_hip.layout_support(geom, self.x_approximate.hip_scheme, 2) & 2):
+            return False
+        bn, conv = next_q[0], next_q[1]
+        if not isinstance(conv, QuantConv2d) or conv.training or conv.w_quant == 'fp' or conv.in_channels != self.out_channels:
+            return False
+        if conv.groups != 1 or isinstance(conv.padding, str) or conv.padding_mode != 'zeros' or conv.weight.device != device:
+            return False
+        if bn is not None and (bn.training or not bn.track_running_stats or bn.running_mean.device != device):
+            return False
+        kh, kw = conv.kernel_size
+        cgeom = _hip.make_geom(n, self.out_channels, ho, wo, conv.out_channels, kh, kw, conv.stride, conv.padding, conv.dilation, 1)
+        if not conv._reads_split3(cgeom, n, _hip) or not (_hip.layout_support(cgeom, conv.x_approximate.hip_scheme, 2) & 4):
+            return False
+        if len(next_q) > 2 and next_q[2] is not None and len(next_q[2]) > 0:
+            return bool(getattr(next_q[2], 'reads_split3', lambda *_: False)(n, self.out_channels, ho, wo))
+        return True
+
+    def _act_planes(self, x, geom, k, n, pre, xq, _hip, x_layout: int = 0):
         """Quantize ``x`` with lsq_act_quant into this module's plane workspace; returns (planes, scales)."""
         # (one workspace per launch stream: two streams through one module must not share planes and scales)
         key = ('act', geom.key()[:4], geom.pad_h, geom.pad_w, self.groups, k, x.device,
@@ -296,7 +330,7 @@ class QuantConv2d(nn.Conv2d):
         forced = xq.eval_scales(n)
         if forced is not None:
             forced = forced.to(device=x.device, dtype=torch.float32).contiguous()
-        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced, pre)
+        _hip.act_quant(x, geom, xq.hip_scheme, k, self.act_skip, self._alpha(), planes, scales, forced, pre, x_layout)
         return planes, scales
 
     def _forward_hip(self, x: torch.Tensor, pre_bn: Optional[nn.BatchNorm2d] = None, relu: bool = False,
@@ -304,19 +338,41 @@ class QuantConv2d(nn.Conv2d):
                      prelu: Optional[torch.Tensor] = None, next_q: Optional[tuple] = None,
                      res_ready: Optional[torch.cuda.Event] = None) -> torch.Tensor:
         from quant import _hip
-        from quant.binary import chain
+        from quant.binary import chain, layouts
         handed = chain.pending(x)                  # (an attribute of the tensor object: read before detach())
+        # three-stream tensors (quant.binary.layouts) among the operands: the records are attributes of the tensor objects
+        x_s3, rp_s3, rq_s3 = layouts.info(x), layouts.info(res_pre), layouts.info(res_post)
         x = x.detach()
         pre = None if pre_bn is None else self._folded_bn(pre_bn)
-        res_pre = None if res_pre is None else res_pre.detach().contiguous()
-        res_post = None if res_post is None else res_post.detach().contiguous()
         n, c, h, w = x.shape
         kh, kw = self.kernel_size
         geom = _hip.make_geom(n, c, h, w, self.out_channels, kh, kw, self.stride, self.padding,
                               self.dilation, self.groups)
         wbits, wsum, wscales, wprep = self._packed_weights(geom, _hip)
         ho, wo = _hip.out_hw(geom)
-        y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
+        x_layout = res_layout = y_layout = _hip.LAYOUT_NCHW
+        if x_s3 is not None:
+            if self._reads_split3(geom, n, _hip):
+                x, x_layout = x_s3.buf, _hip.LAYOUT_SPLIT3
+            else:
+                x = layouts.unpack(x_s3)
+        if rp_s3 is not None or rq_s3 is not None:
+            both = all(r is not None for r, t in ((rp_s3, res_pre), (rq_s3, res_post)) if t is not None)
+            if both and self.x_quant in ('ls-2', 'ls-T') and (_hip.layout_support(geom, self.x_approximate.hip_scheme, 2) & 4):
+                res_pre = None if res_pre is None else rp_s3.buf
+                res_post = None if res_post is None else rq_s3.buf
+                res_layout = _hip.LAYOUT_SPLIT3
+            else:
+                res_pre, res_post = layouts.to_nchw(res_pre) if res_pre is not None else None, layouts.to_nchw(res_post) if res_post is not None else None
+        if res_layout == _hip.LAYOUT_NCHW:
+            res_pre = None if res_pre is None else res_pre.detach().contiguous()
+            res_post = None if res_post is None else res_post.detach().contiguous()
+        if self._split3_output(next_q, geom, n, ho, wo, x.device, _hip):
+            y = layouts.empty(n, self.out_channels, ho, wo, x.device)
+            y_layout = _hip.LAYOUT_SPLIT3
+        else:
+            y = torch.empty((n, self.out_channels, ho, wo), dtype=torch.float32, device=x.device)
+        y_dev = layouts.info(y).buf if y_layout else y
         bias = None if self.bias is None else self.bias.detach()
         def join():                      # residual operands from a side stream: in front of the convolution, behind the quantizer
             if res_ready is not None:
@@ -352,8 +408,8 @@ class QuantConv2d(nn.Conv2d):
                     _hip.xnor_conv2d(planes_in, k, scales_in, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)
                     self.last_act_scales = scales_in
                     return y
-        planes, scales = self._act_planes(x, geom, k, n, pre, xq, _hip)
+        planes, scales = self._act_planes(x, geom, k, n, pre, xq, _hip, x_layout)
         join()
-        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y, relu, res_pre, res_post, prelu)
+        _hip.xnor_conv2d(planes, k, scales, wbits, wsum, wscales, bias, geom, y_dev, relu, res_pre, res_post, prelu, y_layout, res_layout)
         self.last_act_scales = scales
         return y

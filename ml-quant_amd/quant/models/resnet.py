@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from quant import _hip
+from quant.binary import layouts
 from quant.binary.binary_conv import QuantConv2d
 
 non_linearity_map = {'relu': nn.ReLU, 'prelu': nn.PReLU, 'identity': nn.Identity}
@@ -190,6 +191,7 @@ class RegularBasicBlock(nn.Module):
         self.shortcut = _projection(in_planes, planes, stride, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = layouts.to_nchw(x)          # (a three-stream tensor from a fused block in front: this block reads NCHW)
         y = self.nonlin1(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y)) + self.shortcut(x)
         return self.nonlin2(y)          # (batch norm follows the conv here: nothing to fold into the quantizer)
@@ -227,6 +229,7 @@ class XnorBasicBlock(nn.Module):
                 return self.conv2.fused_forward(first, self.bn2, res_post=first, next_q=nxt, **a2)
             first = self.conv1.fused_forward(x, self.bn1, next_q=(self.bn2, self.conv2), **a1)
             return self.conv2.fused_forward(first, self.bn2, res_pre=sc, next_q=nxt, res_ready=sc_ready, **a2)
+        x = layouts.to_nchw(x)          # (a three-stream tensor from a fused block in front: the modules below read NCHW)
         first = self.nonlin1(self.conv1(self.bn1(x)))
         if self.double_shortcut:
             first = first + self.shortcut(x)
@@ -333,7 +336,7 @@ class QResNet(nn.Module):
         # prepare that block's first quantized input (quant.binary.chain)
         for cur, nxt in zip(self.blocks[1:], self.blocks[2:]):
             if isinstance(cur, XnorBasicBlock) and isinstance(nxt, XnorBasicBlock):
-                cur.__dict__['chain_next'] = (nxt.bn1, nxt.conv1)
+                cur.__dict__['chain_next'] = (nxt.bn1, nxt.conv1, nxt.shortcut)
 
     def _make_layer(self, block, layer_config: dict, in_planes: int, out_planes: int, num_blocks: int,
                     nonlins: List[str], stride: int, moving_average_mode: str = 'off',
@@ -352,7 +355,7 @@ class QResNet(nn.Module):
             with chain.scope(x.device):            # (the row-sum accumulators of chained 1-bit layers: one fill per forward)
                 for stage in self.blocks:
                     x = stage(x)
-            return self.linear_classifier(x)
+            return self.linear_classifier(layouts.to_nchw(x))
         for stage in self.blocks:
             x = stage(x)
         return self.linear_classifier(x)

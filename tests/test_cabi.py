@@ -34,7 +34,9 @@ def test_header_declares_the_expected_entry_points():
     assert declared_functions() == sorted([
         'lsq_abi_version', 'lsq_error_string', 'lsq_act_plane_words', 'lsq_weight_plane_words', 'lsq_solver_workspace_bytes', 'lsq_sweep_workspace_bytes',
         'lsq_act_quant', 'lsq_solve_rows', 'lsq_pack_weight', 'lsq_xnor_conv2d', 'lsq_signw_conv2d', 'lsq_signw_weight_bytes', 'lsq_signw_prepare_weight',
-        'lsq_pool_bias_relu_nhwc', 'lsq_stem_conv_pool', 'lsq_pointwise_conv', 'lsq_quant_values', 'lsq_ste_backward', 'lsq_xnor_conv2d_chain'])
+        'lsq_pool_bias_relu_nhwc', 'lsq_stem_conv_pool', 'lsq_pointwise_conv', 'lsq_quant_values', 'lsq_ste_backward', 'lsq_xnor_conv2d_chain',
+        # ABI v11: activation tensors in the three-stream row layout
+        'lsq_split3_stream_floats', 'lsq_layout_support', 'lsq_act_quant_layout', 'lsq_xnor_conv2d_layout'])
 
 
 def test_every_exported_symbol_is_declared_in_a_header(hip):
@@ -65,7 +67,7 @@ def test_library_exports_every_declared_symbol(hip):
     lib = hip.lib()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.lsq_abi_version() == 10
+    assert lib.lsq_abi_version() == 11
     assert lib.lsq_error_string(0) == b'ok'
     assert b'NULL' in lib.lsq_error_string(-1)
 
