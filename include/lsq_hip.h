@@ -83,9 +83,11 @@ typedef struct lsq_conv_geom {
 /*
  * Layouts of fp32 activation tensors (ABI v11).
  *  LSQ_LAYOUT_NCHW    [N][C][H][W], what the reference's modules produce.
- *  LSQ_LAYOUT_SPLIT3  "three-stream rows": a sample's row of M = C*H*W values (flat NCHW index e = c*H*W + h*W + w) is
- *                     stored as three streams of S = lsq_split3_stream_floats(C, H, W) floats, element e at
- *                     (e % 3) * S + e / 3; rows are 3*S floats apart.  Why: the v1 search of quantizer_ls_2 /
+ *  LSQ_LAYOUT_SPLIT3  "three-stream rows": a sample's row of M = C*H*W values (flat NCHW index e = c*H*W + p, p = h*W + w) is
+ *                     stored as three streams of S = lsq_split3_stream_floats(C, H, W) = C * hp floats: element (c, p) in
+ *                     stream s = e % 3 = (c + p) % 3 at s * S + c * hp + p / 3, i.e. per stream and channel a block of hp
+ *                     floats (ceil(H*W / 3) + 3 rounded up to whole 128-byte lines; the tail of a block is padding of
+ *                     any content); rows are 3*S floats apart.  Why: the v1 search of quantizer_ls_2 /
  *                     quantizer_ls_ternary looks at every third element of the row (quant/binary/quantization.py:63,
  *                     skip = 3; optimal.py:121-155) -- in NCHW that is a third of every cache line, i.e. a full read of
  *                     the row; here it is stream 0, one contiguous third.  A tensor that goes from a convolution's
@@ -97,7 +99,7 @@ typedef struct lsq_conv_geom {
  */
 #define LSQ_LAYOUT_NCHW 0
 #define LSQ_LAYOUT_SPLIT3 1
-/* floats per stream of a SPLIT3 row (a multiple of 32, at least ceil(C*H*W / 3) + 8); -1 when H*W % 3 != 1 */
+/* floats per stream of a SPLIT3 row (C blocks of hp floats, hp a multiple of 32); -1 when H*W % 3 != 1 */
 int64_t lsq_split3_stream_floats(int64_t C, int64_t H, int64_t W);
 /* which operands of a call with geometry g may be SPLIT3: bit 0 -- the input of lsq_act_quant_layout(scheme, skip 3, no
  * forced scales, clamp > 0); bit 1 -- y of lsq_xnor_conv2d_layout with kx activation planes; bit 2 -- its residual operands;

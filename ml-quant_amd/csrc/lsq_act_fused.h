@@ -26,7 +26,9 @@ struct FusedArgs {
   const float* forced;      // [2][N] scales given by the caller (moving-average inference): no solve, planes only
   int* trace;               // test hook: chosen sorted position per row (lsq_debug_solver_trace), or null
   int x_s3;                 // 0: rows in NCHW order; else S, the floats per stream of three-stream rows (LSQ_LAYOUT_SPLIT3):
-                            // element e of a row at (e % 3) * S + e / 3, rows 3 S floats apart (fused_act_quant_s3 only)
+                            // element (c, pixel) at ((c + pixel) % 3) * S + c * x_hp + pixel / 3, rows 3 S floats apart
+                            // (fused_act_quant_s3 only)
+  int x_hp;                 // ... floats per channel of a stream (x_s3 = C * x_hp; a multiple of 32)
   int greedy;               // gf-2 (quantization.py:118-148 with k = 2): v1 = mean |x| instead of the solve; planes and
                             // v2 = mean |x - v1 b1| are the 2-bit least-squares scheme's
 };

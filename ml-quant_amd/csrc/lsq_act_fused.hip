@@ -44,16 +44,24 @@
 #define LSQ_WIN_HIST 0
 #endif
 // This file is compiled TWICE (Makefile): as it is -- fused_act_quant, rows in NCHW order -- and with -DLSQ_FUSED_S3=1 --
-// fused_act_quant_s3, the same kernels for rows in the THREE-STREAM layout (LSQ_LAYOUT_SPLIT3, include/lsq_hip.h: element e
-// of the row at (e % 3) * S + e / 3).  There the sub-sample e % 3 == 0 of the v1 search (quantization.py:63, skip = 3) is
-// the first contiguous third of the row: pass 1 reads a third of the bytes (one float4 per four keys instead of three),
-// pass 2 reads all three streams -- 4/3 reads of the row instead of 2.  Keys go to the same registers in the same
-// order and pass 2 sums every pixel's |r| in the same channel order, so planes and scales are the NCHW kernels' bit for bit.
+// fused_act_quant_s3, the same kernels for rows in the THREE-STREAM layout (LSQ_LAYOUT_SPLIT3, include/lsq_hip.h: element
+// (c, pixel) in stream s = (c + pixel) % 3 at s * S + c * hp + pixel / 3, S = C * hp).  There the sub-sample e % 3 == 0 of
+// the v1 search (quantization.py:63, skip = 3; e = c * H W + pixel, H W % 3 == 1) is stream 0, the first contiguous third of
+// the row: pass 1 reads a third of the bytes (one float4 per four keys instead of three; the keys of a channel's block, the
+// pad at its end masked), pass 2 reads all three streams -- 4/3 reads of the row instead of 2.  The solve works on exact
+// integer sums and ranks keys by value, so WHICH lane holds a key does not matter; pass 2 sums every pixel's |r| in the
+// same channel order: planes and scales are the NCHW kernels' bit for bit.
 #ifndef LSQ_FUSED_S3
 #define LSQ_FUSED_S3 0
 #endif
+#if LSQ_FUSED_S3                                   // (developer builds: this translation unit's own phase-clock tables)
+#define g_fused_times g_fused_times_s3
+#define g_win_stats g_win_stats_s3
+#define lsq_debug_read_fused_times lsq_debug_read_fused_times_s3
+#define lsq_debug_read_win_stats lsq_debug_read_win_stats_s3
+#endif
 namespace lsq {
-#if defined(LSQ_PHASE_CLOCKS) && !LSQ_FUSED_S3
+#if defined(LSQ_PHASE_CLOCKS)
 __device__ long long g_fused_times[1024][16];    // constant-rate clock (100 MHz) at the phase marks of each workgroup
 #define FMARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_fused_times[blockIdx.x][i] = (long long)wall_clock64(); } while (0)
 __device__ int g_win_stats[1024][4];             // windowed level 1: 1 solved / 2 fell back, flags, flagged groups, flagged fine bins
@@ -352,15 +360,40 @@ static __device__ __forceinline__ unsigned l1_scan(FusedLds* lds, unsigned n, un
 
 // ---------------------------------------------------------------------------------------------
 // Block path: the sub-sampled keys of the row straight from memory (L2 / Infinity Cache).
+// three-stream rows: entries of channel c in stream 0 = pixels congruent to -c modulo 3 below H W
+static __device__ __forceinline__ unsigned s3_count(unsigned c, unsigned HW) {
+  const unsigned pmin = (3u - c % 3u) % 3u;
+  return (HW - pmin + 2u) / 3u;
+}
 template <class F>
 static __device__ __forceinline__ void for_each_row_key(const FusedArgs& a, const float* __restrict__ xrow, unsigned n, F f) {
   constexpr int U = 8;
+  if constexpr (kS3) {
+    // the sub-sample is stream 0: C blocks of x_hp floats, the first s3_count(c) of each are keys
+    const unsigned hp = (unsigned)a.x_hp, tot = (unsigned)a.C * hp, HW = (unsigned)(a.H * a.W);
+    for (unsigned j0 = threadIdx.x; j0 < tot; j0 += kThreads * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = xrow[min(j0 + (unsigned)u * kThreads, tot - 1u)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned j = j0 + (unsigned)u * kThreads;
+        const unsigned c = j / hp;
+        if (j < tot && j - c * hp < s3_count(c, HW)) {
+          float xv = v[u];
+          if (a.pre_scale) xv = fmaf(xv, a.pre_scale[c], a.pre_shift[c]);
+          f(abs_key(clamp_sym(xv, a.alpha)));
+        }
+      }
+    }
+    return;
+  }
   for (unsigned j0 = threadIdx.x; j0 < n; j0 += kThreads * U) {
     float v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned j = min(j0 + (unsigned)u * kThreads, n - 1u);
-      v[u] = kS3 ? xrow[j] : xrow[(long long)j * 3];     // (three-stream rows: the sub-sample is stream 0)
+      v[u] = xrow[(long long)j * 3];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -1549,23 +1582,23 @@ struct Pf {
 // those loads until most of the 256 KB of its workgroup have arrived -- measured: the phase behind the request grew by
 // exactly what pass 2 saved.  An eighth at a time (32 KB per CU) fits, and the copy runs meanwhile.
 static constexpr int kPfParts = 8;
-// Three-stream rows: where a lane's item -- VEC pixels p0, p0 + 3, ... (one class mod 3: consecutive floats of a stream) x
-// 64 channels -- finds channel c0 + cc: stream (u0 + cc) % 3 at rank (c0 + cc) h + (u0 + cc) / 3 with u0 = c0 + p0, i.e.
-// qb[cc % 3] + (cc / 3) (3 h + 1) from three per-lane pointers.
+// Three-stream rows: where a lane's item -- VEC pixels p0, p0 + 3, ... (one class mod 3: consecutive floats of a stream,
+// starting at a multiple of VEC: aligned loads) x 64 channels -- finds channel c0 + cc: stream (c0 + cc + p0) % 3 at
+// (c0 + cc) hp + p0 / 3, i.e. qb[cc % 3] + cc * hp from three per-lane pointers.
 struct S3Item {
   const float* qb[3];
-  int step;                                                          // 3 h + 1 floats
+  int step;                                                          // hp floats
 };
 static __device__ __forceinline__ S3Item s3_item(const FusedArgs& a, const float* __restrict__ xrow, int c0, int p0) {
-  const unsigned h = (unsigned)(a.H * a.W) / 3u, S = (unsigned)a.x_s3;
+  const unsigned S = (unsigned)a.x_s3, hp = (unsigned)a.x_hp;
   const unsigned u0 = (unsigned)(c0 + p0);
+  const unsigned r0 = u0 - 3u * (__umulhi(u0, 0xAAAAAAABu) >> 1);
+  const float* base = xrow + ((long long)c0 * hp + (__umulhi((unsigned)p0, 0xAAAAAAABu) >> 1));
   S3Item it;
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const unsigned u = u0 + (unsigned)m, q = __umulhi(u, 0xAAAAAAABu) >> 1, r = u - 3u * q;
-    it.qb[m] = xrow + ((long long)r * S + (long long)(c0 + m) * h + q);
-  }
-  it.step = 3 * (int)h + 1;
+  it.qb[0] = base + (long long)r0 * S;
+  it.qb[1] = base + (long long)(r0 == 2u ? 0u : r0 + 1u) * S;
+  it.qb[2] = base + (long long)(r0 == 0u ? 2u : r0 - 1u) * S;
+  it.step = (int)hp;
   return it;
 }
 // item index -> (channel word j, first pixel p0) of a three-stream row: per word 3 * PG items, PG = ceil(HW / (3 VEC))
@@ -1585,7 +1618,7 @@ static __device__ __forceinline__ void pass2_request_part(const float* __restric
 #pragma unroll
   for (int i = lo; i < hi; ++i) {
     constexpr int UB = Pf<VEC>::UB;
-    const float* __restrict__ q = kS3 ? s3->qb[i % 3] + (long long)(i / 3) * s3->step : q0 + (long long)i * HW;
+    const float* __restrict__ q = kS3 ? s3->qb[i % 3] + (long long)i * s3->step : q0 + (long long)i * HW;
     const int b = i / UB, u = i % UB;
     if constexpr (VEC == 4) {
       const float4 t = *reinterpret_cast<const float4*>(q);
@@ -1680,7 +1713,7 @@ static __device__ __forceinline__ double pass2_full(const FusedArgs& a, const fl
       for (int u = 0; u < UB; ++u, q += HW) {
         if constexpr (kS3) {
           const int cc = bb * UB + u;
-          q = s3v.qb[cc % 3] + (long long)(cc / 3) * s3v.step;
+          q = s3v.qb[cc % 3] + (long long)cc * s3v.step;
         }
         if constexpr (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4*>(q);
@@ -1865,10 +1898,11 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
     const float hinv = 1.0f / (float)HW;
     // triples in flight per lane (more in flight measured slower: the histogram atomics of a batch overlap the
     // loads of the next one)
-    constexpr int B = 3;
-    // three-stream rows: the four sub-sampled elements 12 jt + {0, 3, 6, 9} of a lane's step are ONE float4 of stream 0
-    // (ranks 4 jt .. 4 jt + 3) -- a third of the bytes, the same keys in the same registers
-    const unsigned nvec0 = kS3 ? (unsigned)a.x_s3 / 4u : 0u;
+    constexpr int B = kS3 ? 9 : 3;                 // (three-stream rows: the same 144 bytes per lane in flight)
+    // three-stream rows: a lane's step is ONE float4 of stream 0 -- four entries of one channel's block, keys up to the
+    // channel's count (s3_count), a third of the bytes
+    const unsigned nvec0 = kS3 ? (unsigned)a.x_s3 / 4u : 0u, hp4 = kS3 ? (unsigned)a.x_hp / 4u : 1u;
+    const unsigned hp4_magic = (unsigned)((0x100000000ull + hp4 - 1u) / hp4);      // jt / hp4 = umulhi(jt, magic): exact while jt * hp4 < 2^32
 #pragma unroll
     for (int u0 = 0; u0 < U; u0 += B) {
       float4 v[B][kS3 ? 1 : 3];
@@ -1891,6 +1925,28 @@ static __device__ __forceinline__ void run(const FusedArgs& a, FusedLds* lds) {
           const unsigned e0 = 12u * jt;
           float xs[4] = {v[b][0].x, kS3 ? v[b][0].y : v[b][0].w, kS3 ? v[b][0].z : v[b][kS3 ? 0 : 1].z,
                          kS3 ? v[b][0].w : v[b][kS3 ? 0 : 2].y};
+          if constexpr (kS3) {
+            const unsigned ch = min(__umulhi(jt, hp4_magic), (unsigned)a.C - 1u);
+            const unsigned t0 = 4u * (jt - ch * hp4), cnt = s3_count(ch, (unsigned)HW);
+            float sc = 1.f, sh = 0.f;
+            if (affine) {
+              sc = bn_lds ? lds->bn_s[ch] : a.pre_scale[ch];
+              sh = bn_lds ? lds->bn_t[ch] : a.pre_shift[ch];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const bool has = jt < nvec0 && t0 + (unsigned)e < cnt;
+              const unsigned key = abs_key(clamp_sym(affine ? fmaf(xs[e], sc, sh) : xs[e], a.alpha));
+              if (has) {
+                if (win) hist_add_win(lds, key, win_k0, win_sh, low_base);
+                else hist_add(lds, key);
+                mk = min(mk, key);
+                xk = max(xk, key);
+              }
+              kreg[4 * (u0 + b) + e] = has ? key : kNoKey;
+            }
+            continue;
+          }
           if (affine) {
             // channel of element e0 (e0 / HW via a reciprocal, corrected); the other three sub-sampled elements
             // are at most one channel boundary further each (HW >= 4).  Scale / shift come from the LDS copy.
@@ -2210,8 +2266,8 @@ int fused_act_quant_s3(const FusedArgs& a_in, hipStream_t st) {
   FusedArgs a = a_in;
   // three-stream rows: the solving kernels only (given scales and gf-2 read the row once as it is); H W = 3 h + 1, streams
   // of S floats (a multiple of 4, at least ceil(M / 3) + 8: pass 2's last items read a few floats past a stream's end)
-  if (a.forced || a.greedy || a.x_s3 <= 0 || a.x_s3 % 4 || ((long long)a.H * a.W) % 3 != 1 ||
-      a.x_s3 < (a.row_elems + 2) / 3 + 8 || (a.cg & 63) != 0 || a.C > kBnCap)
+  if (a.forced || a.greedy || a.x_s3 <= 0 || a.x_hp <= 0 || a.x_hp % 32 || a.x_s3 != (long long)a.C * a.x_hp ||
+      ((long long)a.H * a.W) % 3 != 1 || a.x_hp < ((long long)a.H * a.W + 2) / 3 + 3 || (a.cg & 63) != 0 || a.C > kBnCap)
     return kFusedNotEligible;
 #else
 int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
@@ -2260,10 +2316,15 @@ int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
 #else
   if (!a.win_sh) return kFusedNotEligible;           // (rows under a symmetric clamp: the windowed kernels, with their fall-back)
 #endif
-  const long long ntrip = (M / 4 + 2) / 3;
+  const long long ntrip = kS3 ? a.x_s3 / 4 : (M / 4 + 2) / 3;
   const long long need = (ntrip + T - 1) / T;        // triples (4 keys each) per lane
 #ifdef LSQ_DEV_U
   return need <= LSQ_DEV_U ? launch<T, LSQ_DEV_U>(a, vec, st) : kFusedNotEligible;
+#else
+#if LSQ_FUSED_S3
+  if (need <= 18) return launch<T, 18>(a, vec, st);     // (28 x 28 x 128: 128 blocks of 288 floats = 18 float4 per lane)
+  if (need <= 33) return launch<T, 33>(a, vec, st);
+  return kFusedNotEligible;
 #else
   if (need <= 5) return launch<T, 5>(a, vec, st);
   if (need <= 9) return launch<T, 9>(a, vec, st);
@@ -2271,9 +2332,10 @@ int fused_act_quant(const FusedArgs& a_in, hipStream_t st) {
   if (need <= 33) return launch<T, 33>(a, vec, st);
   return kFusedNotEligible;
 #endif
+#endif
 }
 
-#if defined(LSQ_PHASE_CLOCKS) && !LSQ_FUSED_S3
+#if defined(LSQ_PHASE_CLOCKS)
 extern "C" int lsq_debug_read_fused_times(long long* host16384) {
   return (int)hipMemcpyFromSymbol(host16384, HIP_SYMBOL(g_fused_times), 16384 * sizeof(long long));
 }

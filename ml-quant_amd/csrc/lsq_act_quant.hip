@@ -1897,6 +1897,7 @@ static int act_quant_impl(const float* x, int x_layout, const lsq_conv_geom* g, 
       const int64_t S = lsq_split3_stream_floats(g->C, g->H, g->W);
       if (S <= 0 || !solver || ((uintptr_t)x % 16) != 0) return LSQ_E_UNSUPPORTED;
       f.x_s3 = (int)S;
+      f.x_hp = (int)(S / g->C);
       const int e = fused_act_quant_s3(f, st);
       return e == kFusedNotEligible ? LSQ_E_UNSUPPORTED : e;
     }

@@ -30,6 +30,7 @@ struct ConvArgs {
   // ---- three-stream rows (LSQ_LAYOUT_SPLIT3, include/lsq_hip.h): 0 = NCHW, else S = floats per stream of the tensor's rows
   int y_s3;                            // layout of y (and of the partial sums read back with `accumulate`)
   int res_s3;                          // layout of res_pre / res_post (both)
+  int s3_hp;                           // floats per channel of a stream (S = O * s3_hp)
   // ---- chained 1-bit layers (lsq_xnor_conv2d_chain): the NEXT layer's ls-1 quantizer in this layer's epilogue, and this
   // layer's activation scale from the exact row sum the PREVIOUS layer's epilogue left
   const long long* xunits;             // [N] or null: row sum of |clamp(x)| in units of 2^e; xscale = float(units * xunit / xM)

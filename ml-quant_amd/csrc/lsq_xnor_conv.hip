@@ -293,6 +293,7 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
     // three-stream rows (include/lsq_hip.h): the integer-MFMA kernel only
     const int64_t S = lsq_split3_stream_floats(g->O, Ho, Wo);
     if (S <= 0 || 3 * S * g->N >= (1ll << 31) || g_force_popcount.load(std::memory_order_relaxed) || x_units || next) return LSQ_E_UNSUPPORTED;
+    a.s3_hp = (int)(S / g->O);
     a.y_s3 = y_layout == LSQ_LAYOUT_SPLIT3 ? (int)S : 0;
     a.res_s3 = res_layout == LSQ_LAYOUT_SPLIT3 ? (int)S : 0;
   }
@@ -369,8 +370,9 @@ extern "C" int lsq_xnor_conv2d_layout(const uint64_t* xplanes, int kx, const flo
 
 extern "C" int64_t lsq_split3_stream_floats(int64_t C, int64_t H, int64_t W) {
   if (C <= 0 || H <= 0 || W <= 0 || (H * W) % 3 != 1) return -1;
-  const int64_t n0 = (C * H * W + 2) / 3;
-  return (n0 + 8 + 31) / 32 * 32;
+  // per channel and stream ceil(H W / 3) values (+ 3: the quantizer's last items read a float4 that starts at the last one),
+  // rounded up to whole 128-byte lines
+  return C * (((H * W + 2) / 3 + 3 + 31) / 32 * 32);
 }
 
 extern "C" int lsq_layout_support(const lsq_conv_geom* g, int scheme, int kx) {
@@ -380,7 +382,7 @@ extern "C" int lsq_layout_support(const lsq_conv_geom* g, int scheme, int kx) {
   // bit 0: the single-launch solving quantizer (lsq_act_fused.hip) on three-stream rows
   const long long M = (long long)g->C * g->H * g->W;
   if ((scheme == LSQ_SCHEME_LS2 || scheme == LSQ_SCHEME_LST) && lsq_split3_stream_floats(g->C, g->H, g->W) > 0 && cg % 64 == 0 &&
-      g->C <= 1024 && M % 4 == 0 && (long long)g->H * g->W >= 4 && ((M / 4 + 2) / 3 + 511) / 512 <= 33)
+      g->C <= 1024 && M % 4 == 0 && (long long)g->H * g->W >= 4 && (lsq_split3_stream_floats(g->C, g->H, g->W) / 4 + 511) / 512 <= 33)
     mask |= 1;
   // bits 1, 2: the integer-MFMA convolution's three-stream kernels (lsq_xnor_mfma.hip)
   const int Ho = out_h(g), Wo = out_w(g);

@@ -27,6 +27,9 @@
 // ONE pixel (column lane & 31) and 16 out-channels (rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
 
 #include "lsq_xnor_conv.h"
+#ifndef LSQ_Y3_WAVES
+#define LSQ_Y3_WAVES 12
+#endif
 
 namespace lsq {
 namespace {
@@ -43,14 +46,20 @@ constexpr unsigned kM0 = 0x01010101u;
 // 512 channels (the fragments of 512 channels fill the LDS of a CU; at 256 channels one workgroup of 8 waves expands
 // the weights and builds the tables ONCE where two workgroups of 4 did it twice: 59-60 -> 55-56 us per 14 x 14 layer, round 4).
 //
-// S3: kernels that read / write fp32 tensors in the THREE-STREAM ROW layout (include/lsq_hip.h, LSQ_LAYOUT_SPLIT3): element e
-// of a sample's row (e = c * HoWo + pixel) lives at (e % 3) * S + e / 3, so that the sub-sample e % 3 == 0 the next layer's
-// scale solve reads (quantization.py:63, skip = 3) is ONE contiguous third of the row instead of every third float of all of
-// it.  HoWo % 3 == 1 (every ResNet shape), hence e % 3 = (c + pixel) % 3 and e / 3 = c * h3 + (c + pixel) / 3, h3 = HoWo / 3.
-// When the OUTPUT has that layout a tile is 32 pixels at stride 3 -- flat pixel 96 (tile / 3) + tile % 3 + 3 lane --, so the
-// 32 lanes of a channel's store are 32 consecutive floats of one stream, as coalesced as the NCHW store; the bit-plane reads
-// of such a tile are the 32 lanes' 24-byte windows back to back (no overlap inside a tile; the three tiles of a group of 96
-// pixels read the same lines shifted by one word).  Residual operands may have either layout.
+// S3: kernels that read / write fp32 tensors in the THREE-STREAM ROW layout (include/lsq_hip.h, LSQ_LAYOUT_SPLIT3): element
+// (c, pixel) of a sample's row lives in stream s = (c + pixel) % 3 at s * S + c * hp + pixel / 3 (hp floats per channel and
+// stream, a multiple of 32; S = C * hp), so that the sub-sample e % 3 == 0 of the flat NCHW index e = c * HoWo + pixel --
+// what the next layer's scale solve reads (quantization.py:63, skip = 3) -- is ONE contiguous third of the row instead of
+// every third float of all of it: HoWo % 3 == 1 (every ResNet shape), hence e % 3 = (c + pixel) % 3.
+// When the OUTPUT has that layout a tile is 32 pixels at stride 3 of ONE image -- pixel 96 group + j + 3 lane, j = 0, 1, 2,
+// ceil(HoWo / 96) groups per image --, so the 32 lanes of a channel's store are 32 consecutive floats of one stream that
+// START ON A 128-BYTE LINE (the first version -- e at (e % 3) S + e / 3, groups running across images -- had them start
+// anywhere: every line was written by two tiles on two CUs, and the launch took 110 us against 75).  The bit-plane reads
+// of such a tile are the 32 lanes' 24-byte windows back to back: 768 bytes without overlap where 32 neighbouring pixels share
+// all but 272 -- so the three tiles of a group, which read the same lines shifted by one word, go to three waves of ONE
+// workgroup at the same time (wave = (slot, j), NWAVES = 6: two groups per workgroup and round) and meet in the CU's L1; on
+// three different CUs (the first version) the planes went through the L2s 2.8 times and the 56 x 56 layers took 141 us
+// against 92.  Residual operands may have either layout.
 template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN, bool YS3, bool RS3>
 __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
   constexpr bool S3 = YS3 || RS3;                // (which operands have the three-stream layout is fixed per instantiation:
@@ -74,14 +83,18 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   const unsigned total = (unsigned)(a.N * a.Ho * a.Wo);
   const int HoWo = a.Ho * a.Wo;
   constexpr bool map3 = YS3;                     // tiles of 32 pixels at stride 3: the output is a three-stream tensor
-  const int ntiles = map3 ? 3 * (int)((total + 95u) / 96u) : (int)((total + 31u) >> 5);
-  const unsigned s3_S = (unsigned)(a.y_s3 ? a.y_s3 : a.res_s3), s3_h = (unsigned)HoWo / 3u;    // floats per stream; HoWo = 3 h + 1
+  // (stride-3 tiles: `tile` counts GROUPS of 96 pixels, the wave's j picks its third)
+  const int GPI = (HoWo + 95) / 96;              // stride-3 tiles: groups per image
+  const int ntiles = map3 ? a.N * GPI : (int)((total + 31u) >> 5);
+  constexpr int kSlots = map3 ? NWAVES / 3 : NWAVES;       // tiles (groups) a workgroup works on at a time
+  static_assert(!map3 || NWAVES % 3 == 0, "stride-3 tiles: three waves per group");
+  const int wslot = map3 ? wid / 3 : wid, j3 = map3 ? wid - 3 * (wid / 3) : 0;
+  const unsigned s3_S = (unsigned)(a.y_s3 ? a.y_s3 : a.res_s3), s3_h = (unsigned)a.s3_hp;      // floats per stream / per channel of a stream
   const unsigned* __restrict__ xd = reinterpret_cast<const unsigned*>(a.xplanes);
   const unsigned plane_stride = 2u * (unsigned)a.xplane_words;
-  const int tstride = gridDim.x * NWAVES;
+  const int tstride = gridDim.x * kSlots;
   // a wave's pixel index advances by the same amount from tile to tile: (n, ho, wo) follow with adds and carries
-  // (stride-3 tiles: tstride is a multiple of 3 -- the launcher sees to it --, so tile % 3 stays and the step is the same)
-  const unsigned dstep = 32u * (unsigned)tstride;
+  const unsigned dstep = (map3 ? 96u : 32u) * (unsigned)tstride;
   const int d_n = (int)(dstep / (unsigned)HoWo);
   const int d_r = (int)(dstep - (unsigned)d_n * (unsigned)HoWo);
   const int d_ho = d_r / a.Wo, d_wo = d_r - d_ho * a.Wo;
@@ -131,8 +144,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 
   // Element offset of (sample, out-channel o0 + ob + k, the lane's pixel) = v[k % 3] + koff(k), koff uniform: NCHW
   // v[.] = ((n O + o0 + ob) HoWo + pixel), koff = k HoWo; three streams: with u = o0 + ob + pixel, channel k sits in stream
-  // (u + k) % 3 at rank (o0 + ob + k) h + (u + k) / 3, and (u + k) / 3 = k / 3 + (u + k % 3) / 3 -- so v[m] = n * 3 S +
-  // ((u + m) % 3) S + (u + m) / 3 + (o0 + ob) h and koff = k h + k / 3.
+  // (u + k) % 3 at (o0 + ob + k) hp + pixel / 3 -- so v[m] = n * 3 S + ((u + m) % 3) S + (o0 + ob) hp + pixel / 3, koff = k hp.
   struct Lay {
     unsigned v[S3 ? 3 : 1];
   };
@@ -140,11 +152,11 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     if constexpr (S3) {
       if (s3) {
         const unsigned u0 = (unsigned)(o0 + ob) + pix;
-        const unsigned q0 = __umulhi(u0, 0xAAAAAAABu) >> 1, r0 = u0 - 3u * q0;
-        const unsigned base = (unsigned)ln * 3u * s3_S + (unsigned)(o0 + ob) * s3_h + q0;
+        const unsigned r0 = u0 - 3u * (__umulhi(u0, 0xAAAAAAABu) >> 1);
+        const unsigned base = (unsigned)ln * 3u * s3_S + (unsigned)(o0 + ob) * s3_h + (__umulhi(pix, 0xAAAAAAABu) >> 1);
         L.v[0] = base + r0 * s3_S;
-        L.v[1] = base + (r0 == 2u ? 1u : (r0 + 1u) * s3_S);
-        L.v[2] = base + (r0 == 0u ? 2u * s3_S : (r0 == 1u ? 1u : s3_S + 1u));
+        L.v[1] = base + (r0 == 2u ? 0u : r0 + 1u) * s3_S;
+        L.v[2] = base + (r0 == 0u ? 2u : r0 - 1u) * s3_S;
         return;
       }
     }
@@ -156,18 +168,31 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
   // (uniform) element offset of register i's channel k = (i & 3) + 8 (i >> 2) on top of Lay::v[k % 3]
   auto koff = [&](int i, bool s3) -> long long {
     const int k = (i & 3) + 8 * (i >> 2);
-    return (S3 && s3) ? (long long)k * s3_h + k / 3 : (long long)k * HoWo;
+    return (S3 && s3) ? (long long)k * s3_h : (long long)k * HoWo;
   };
   auto kv = [&](const Lay& L, int i) -> unsigned { return L.v[S3 ? ((i & 3) + 8 * (i >> 2)) % 3 : 0]; };
 
   // wave-major numbering: when the tiles do not divide evenly, the waves with one tile more sit in different
   // workgroups (on different SIMDs) instead of filling one
-  int tile = wid * gridDim.x + blockIdx.x;
+  int tile = wslot * gridDim.x + blockIdx.x;
   const bool have_tile = tile < ntiles;
+  // stride-3 tiles: group `t` = (image t / GPI, group t % GPI of that image); lanes past the image's last pixel (its last
+  // group: 3136 = 32 * 96 + 64) are marked like the lanes past the last pixel of all, n = N
+  auto pix3 = [&](int t) {
+    const int gn = t / GPI, gi = t - gn * GPI;
+    const int p = 96 * gi + j3 + 3 * col;
+    Pix px;
+    const bool in = p < HoWo;
+    px.n = in ? gn : a.N;
+    px.ho = in ? (int)((unsigned)p / (unsigned)a.Wo) : 0;
+    px.wo = in ? p - px.ho * a.Wo : 0;
+    return px;
+  };
   Pix cur;
-  {
-    const unsigned p = map3 ? (unsigned)(tile / 3) * 96u + (unsigned)(tile % 3) + 3u * (unsigned)col
-                            : (unsigned)tile * 32u + (unsigned)col;
+  if constexpr (map3) {
+    cur = pix3(tile);
+  } else {
+    const unsigned p = (unsigned)tile * 32u + (unsigned)col;
     cur.n = (int)(p / (unsigned)HoWo);
     const int r = (int)(p - (unsigned)cur.n * (unsigned)HoWo);
     cur.ho = (int)((unsigned)r / (unsigned)a.Wo);
@@ -292,7 +317,10 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     const int nxt = tile + tstride;
     const bool more = nxt < ntiles;
     Pix nx = cur;
-    if (more) advance(nx);
+    if (more) {
+      if constexpr (map3) nx = pix3(nxt);
+      else advance(nx);
+    }
 
     // What the epilogue reads from memory is requested NOW, a whole tile of MFMAs ahead: the two waves of a SIMD run
     // in lockstep (same start, same tile length), so a load waited for in the epilogue stalls the matrix core for
@@ -540,6 +568,23 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 #endif
 }
 
+// three-stream OUTPUT: workgroups of six waves (two groups of 96 pixels at a time), two per CU -- the same three waves per
+// SIMD and 168 registers as the NCHW kernels
+template <int KX, int GG>
+int launch_y3(const ConvArgs& a, hipStream_t st) {
+  constexpr int NWAVES = LSQ_Y3_WAVES, WPC = 3, kSlots = NWAVES / 3;   // (WPC: waves per SIMD the registers must allow)
+  const long long total = (long long)a.N * a.Ho * a.Wo;
+  const long long ngroups = (long long)a.N * (((long long)a.Ho * a.Wo + 95) / 96);
+  const int n_ot = a.O / 32;
+  long long gx = (256 * (12 / NWAVES) + n_ot - 1) / n_ot;
+  if (gx * kSlots > ngroups) gx = (ngroups + kSlots - 1) / kSlots;
+  gx = gx < 1 ? 1 : gx;
+  const dim3 grid((unsigned)gx, (unsigned)n_ot), block(64 * NWAVES);
+  if (a.res_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, false>), grid, block, 0, st, a);
+  return (int)hipGetLastError();
+}
+
 template <int KX, int GG>
 int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int NWAVES = GG >= 4 ? 8 : 4;
@@ -560,15 +605,8 @@ int launch(const ConvArgs& a, hipStream_t st) {
     // rows are the long ones); a three-stream OUTPUT means tiles at pixel stride 3, whose bookkeeping wants the tile stride
     // of a wave to be a multiple of 3
     if constexpr (KX == 2 && GG <= 2) {
-      if (a.y_s3) {
-        const long long nt3 = 3 * ((total + 95) / 96);
-        if (gx * NWAVES > nt3) gx = (nt3 + NWAVES - 1) / NWAVES;
-        if ((gx * NWAVES) % 3) gx = gx >= 3 ? gx - gx % 3 : 3;
-      }
-      const dim3 grid((unsigned)gx, (unsigned)n_ot), block(64 * NWAVES);
-      if (a.y_s3 && a.res_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, true>), grid, block, 0, st, a);
-      else if (a.y_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, false>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, true>), grid, block, 0, st, a);
+      if (a.y_s3) return launch_y3<KX, GG>(a, st);
+      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
       return (int)hipGetLastError();
     } else {
       return kXnorMfmaNoLayout;

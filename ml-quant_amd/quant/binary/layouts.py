@@ -2,7 +2,9 @@
 
 Between a quantized convolution and the next layer's quantizer the fused eval path may keep an activation tensor in a
 layout in which the sub-sample the v1 search reads (every third element of a sample's row, quantization.py:63) is one
-contiguous third of the row: element ``e`` of the row (flat NCHW index) lives at ``(e % 3) * S + e // 3``.  Such a tensor
+contiguous third of the row: element ``(c, p)`` of the row (flat NCHW index ``e = c * H W + p``) lives in stream
+``e % 3 = (c + p) % 3`` at ``(e % 3) * S + c * hp + p // 3`` -- per stream and channel a block of ``hp`` floats that starts on a
+128-byte line, ``S = C * hp``.  Such a tensor
 never leaves the fused path: it is produced by ``lsq_xnor_conv2d_layout``, read by ``lsq_act_quant_layout`` (the solve then
 reads 4/3 of the row instead of twice all of it), by a later convolution's epilogue as a residual operand and by the
 projection shortcut, and anything else that receives one calls :func:`to_nchw` first.
@@ -16,9 +18,12 @@ from typing import Optional
 
 import torch
 
-#: keep tensors in the three-stream layout between fused kernels (False: NCHW everywhere, the round-5 data flow -- the
-#: comparator of tests/test_gpu_round6.py: logits are bit-identical either way)
-ENABLED = True
+#: keep tensors in the three-stream layout between fused kernels.  OFF by default: measured on the headline network
+#: (scripts/split3_ab.py, profiles/r06_split3_*.txt) the solve's first pass turns out to be bound by its per-key work, not by
+#: the bytes it reads (29 -> 20 us at 56 x 56 for a third of the bytes, 5 us per launch inside the network), and the
+#: convolution that writes the layout pays more than that (stride-3 tiles: +4 ... +20 us per launch) -- 2.37 -> 2.52 ms per
+#: step.  Logits are bit-identical either way (tests/test_gpu_round6.py runs both).
+ENABLED = False
 
 _ATTR = '_lsq_split3'
 
@@ -56,14 +61,18 @@ def info(t: Optional[torch.Tensor]) -> Optional[Split3]:
 _index_cache = {}
 
 
-def _index(m: int, S: int, device) -> torch.Tensor:
-    key = (m, S, str(device))
+def _index(shape, S: int, device) -> torch.Tensor:
+    """Position of every element of a row (in flat NCHW order) inside the row's 3 S floats."""
+    _, c, h, w = shape
+    key = (c, h, w, S, str(device))
     idx = _index_cache.get(key)
     if idx is None:
         if len(_index_cache) >= 32:
             _index_cache.clear()
-        e = torch.arange(m, dtype=torch.int64, device=device)
-        idx = _index_cache[key] = (e % 3) * S + e // 3
+        hp = S // c
+        ch = torch.arange(c, dtype=torch.int64, device=device).view(-1, 1)
+        p = torch.arange(h * w, dtype=torch.int64, device=device).view(1, -1)
+        idx = _index_cache[key] = (((ch + p) % 3) * S + ch * hp + p // 3).reshape(-1)
     return idx
 
 
@@ -76,7 +85,7 @@ def to_nchw(t: torch.Tensor) -> torch.Tensor:
 
 def unpack(rec: Split3) -> torch.Tensor:
     n, c, h, w = rec.shape
-    return rec.buf[:, _index(c * h * w, rec.S, rec.buf.device)].view(n, c, h, w)
+    return rec.buf[:, _index(rec.shape, rec.S, rec.buf.device)].view(n, c, h, w)
 
 
 def from_nchw(x: torch.Tensor) -> torch.Tensor:
@@ -85,5 +94,5 @@ def from_nchw(x: torch.Tensor) -> torch.Tensor:
     t = empty(n, c, h, w, x.device)
     rec = info(t)
     rec.buf.zero_()
-    rec.buf[:, _index(c * h * w, rec.S, x.device)] = x.reshape(n, -1).to(torch.float32)
+    rec.buf[:, _index(rec.shape, rec.S, x.device)] = x.reshape(n, -1).to(torch.float32)
     return t

@@ -2,7 +2,8 @@
 quantized convolution's epilogue and the next layer's quantizer.  The layout changes ADDRESSES only, so every check is
 bit-for-bit: the convolution's three-stream output unpacked == its NCHW output, the quantizer's planes and scales from a
 three-stream input == those from the NCHW input (and v1 == the exact oracle), and the whole network with the layout on ==
-the network with it off (the round-5 data flow, kept behind ``quant.binary.layouts.ENABLED`` as the comparator)."""
+the network with it off (the round-5 data flow and the default, ``quant.binary.layouts.ENABLED``: the layout measured
+slower end to end -- DESIGN.md section 4.9)."""
 
 import numpy as np
 import pytest
@@ -49,9 +50,11 @@ def test_three_stream_round_trip_and_stream_zero_is_the_sub_sample():
         rec = L.info(t)
         assert rec.S % 32 == 0 and rec.buf.shape == (shape[0], 3 * rec.S)
         assert torch.equal(L.to_nchw(t), x)
-        m = shape[1] * shape[2] * shape[3]
-        sub = x.reshape(shape[0], -1)[:, ::3]
-        assert torch.equal(rec.buf[:, :(m + 2) // 3], sub)
+        # stream 0, pads removed, is the sub-sample in order: channel c's block holds its pixels congruent to -c modulo 3
+        hp, hw = rec.S // shape[1], shape[2] * shape[3]
+        s0 = rec.buf[:, :rec.S].view(shape[0], shape[1], hp)
+        got = torch.cat([s0[:, c, :(hw - (-c) % 3 + 2) // 3] for c in range(shape[1])], dim=1)
+        assert torch.equal(got, x.reshape(shape[0], -1)[:, ::3])
     assert L.stream_floats(64, 6, 6) == -1          # 36 % 3 == 0: no such layout
 
 
@@ -159,7 +162,7 @@ def test_three_stream_operands_outside_the_kernels_are_refused():
     pl = torch.zeros((2 * hip.act_plane_words(g2),), dtype=torch.int64, device=DEV)
     sc = torch.empty((2, 2), dtype=torch.float32, device=DEV)
     with pytest.raises(hip.LsqHipError):
-        hip.act_quant(torch.zeros((2, 3 * 800), device=DEV), g2, hip.SCHEME_LS2, 2, 3, 3.0, pl, sc, None, None, 1)
+        hip.act_quant(torch.zeros((2, 3 * 64 * 32), device=DEV), g2, hip.SCHEME_LS2, 2, 3, 3.0, pl, sc, None, None, 1)
     # an ls-1 quantizer has no solve: nothing to gain, refused
     g3 = hip.make_geom(2, 64, 14, 14, 64, 3, 3, (1, 1), (1, 1), (1, 1), 1)
     with pytest.raises(hip.LsqHipError):
@@ -183,16 +186,13 @@ def test_whole_network_with_three_stream_tensors_is_bit_identical(act):
     for batch in (6, 33):
         x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(batch)).to(DEV)
         with torch.no_grad():
-            L.ENABLED = False
-            try:
-                want = model(x).clone()
-            finally:
-                L.ENABLED = True
-            L.empty = spy
+            assert L.ENABLED is False                    # (the default: round 5's data flow)
+            want = model(x).clone()
+            L.ENABLED, L.empty = True, spy
             try:
                 got = model(x).clone()
             finally:
-                L.empty = orig
+                L.ENABLED, L.empty = False, orig
         assert torch.equal(got, want), (act, batch, float((got - want).abs().max()))
     assert (64, 56) in seen and (128, 28) in seen, seen
 
@@ -206,15 +206,13 @@ def test_three_stream_tensor_leaving_the_fused_path_is_unpacked():
     x = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(4)).to(DEV)
     with torch.no_grad():
         h0 = model.blocks[0](x)
-        h1 = model.blocks[1](h0)                        # fused block: its output is a three-stream tensor
-        assert L.info(h1) is not None
-        want = model.blocks[1](h0)
-        L.ENABLED = False
+        plain = model.blocks[1](h0)
+        L.ENABLED = True
         try:
-            plain = model.blocks[1](h0)
+            h1 = model.blocks[1](h0)                    # fused block: its output is a three-stream tensor
         finally:
-            L.ENABLED = True
-        assert L.info(plain) is None and torch.equal(L.to_nchw(h1), plain)
+            L.ENABLED = False
+        assert L.info(h1) is not None and L.info(plain) is None and torch.equal(L.to_nchw(h1), plain)
         resnet.FUSE_BLOCKS = False
         try:
             a = model.blocks[2](h1)                     # modular path: must unpack
