@@ -506,7 +506,7 @@ def main():
     # the first step of every group of steps only (an event pair costs a few microseconds of stream time).
     single = None
     table, by_shape, timed_table = {}, {}, {}
-    if nstreams > 1 or roofline:
+    if nstreams > 1 or roofline or world > 1:            # (N > 1: the line always carries the one-stream figure beside the pipelined one)
         one = StreamPipeline(lambda shard: local_forward(model, shard), device, 1)
 
         def run_single(n, sample_every=0):
@@ -591,9 +591,12 @@ def main():
             'launcher': {'kind': launcher, 'ranks': world, 'numa_pinning_rank0': pinned},
             'path_frac': value / world / PATH_ROOFLINE_IMG_S[args.act],
         }
-        if nstreams > 1:
+        if nstreams > 1 or world > 1:
             out['pipelined'] = {'streams': nstreams, 'value': value, 'ms_per_step': out['ms_per_step'],
                                 'vs_single_stream': value / single['value'] if single else None}
+        out['value_definition'] = ('whole-job images/s of the headline region: consecutive steps on %d HIP stream(s), the product\'s evaluate '
+                                   'path (rounds 1-4 reported the one-stream step: `single_stream`, timed on the same footing -- '
+                                   'uninstrumented bracket of --steps steps, barrier + synchronize on both sides)' % nstreams)
         if single is not None:
             out['single_stream'] = single
         if not cuda:

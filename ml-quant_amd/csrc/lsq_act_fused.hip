@@ -1010,13 +1010,15 @@ static __device__ __forceinline__ void hist_add_win(FusedLds* lds, unsigned key,
   // one atomic per key, its address and operand selected (a branch per key costs more than the selects)
   const unsigned t = key - k0;
   const bool in = key >= k0;
-  const unsigned idx = in ? t >> sh : low_base + (key >> 23);
+  const unsigned idx = in ? min(t >> sh, (unsigned)L1_BINS - 1u) : low_base + (key >> 23);
   const unsigned low = in ? (t & ((1u << sh) - 1u)) : (key & 0x7FFFFFu);
   atomicAdd(&lds->a.hist1[idx], kOne | (unsigned long long)low);
 #else
   if (key >= k0) {
     const unsigned t = key - k0;
-    atomicAdd(&lds->a.hist1[t >> sh], kOne | (unsigned long long)(t & ((1u << sh) - 1u)));
+    // (min: every key is at most key(alpha) -- the clamp maps a NaN to -alpha, fminf(fmaxf(NaN, -a), a) --, so the index is below
+    //  L1_BINS by construction; the bound keeps a build with other NaN semantics from writing past the histogram)
+    atomicAdd(&lds->a.hist1[min(t >> sh, (unsigned)L1_BINS - 1u)], kOne | (unsigned long long)(t & ((1u << sh) - 1u)));
   } else {                                       // below the window (rare): one bin per binade, the 23 mantissa bits summed
     atomicAdd(&lds->a.hist1[low_base + (key >> 23)], kOne | (unsigned long long)(key & 0x7FFFFFu));
   }

@@ -120,7 +120,7 @@ template <int SPLIT>
 struct StemLds {
   unsigned xs[SPLIT][3 * kIR * kIC / 2];  // bf16 pairs of each split term, [c][row][col]
   float hbuf[kCR][kO][kHS];               // horizontal 3-max (stride 2) of every conv row of the chunk (rows padded: bank spread)
-  float carry[kCR][2][2][16];             // last conv column of the previous chunk: [row][out-channel tile][32 out-channels]
+  float carry[kCR][2][32];                 // last conv column of the previous chunk: [row][out-channel tile][32 out-channels]
   float bias[kO];
 };
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       }
     }
   }
-  for (int i = tid; i < kCR * kO; i += 256) (&lds.carry[0][0][0][0])[i] = ninf;
+  for (int i = tid; i < kCR * kO; i += 256) (&lds.carry[0][0][0])[i] = ninf;
   if (tid < kO) lds.bias[tid] = a.bias[tid];
 
   const float* __restrict__ xn = a.x + (long long)n * 3 * a.H * a.W;
@@ -306,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
       }
       float prevA = 0.f, prevB = 0.f;                          // column 31 of the previous chunk (32 floats per row and tile)
       if (g == 0) {
-        prevA = lds.carry[qA][mt][0][xl_];
-        if (PAIR) prevB = lds.carry[min(qB, kCR - 1)][mt][0][xl_];
+        prevA = lds.carry[qA][mt][xl_];
+        if (PAIR) prevB = lds.carry[min(qB, kCR - 1)][mt][xl_];
       }
       float lo_from_hi[4], hi_from_lo[4];
 #pragma unroll
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_pool_kernel(StemArgs a) {   
         if (second ? okB : okA)
           *reinterpret_cast<float2*>(&lds.hbuf[second ? min(qB, kCR - 1) : qA][ch][4 * Gc + 2 * g]) = make_float2(ca, cb);
       }
-      if (!PAIR && g == 1) lds.carry[qA][mt][0][xl_] = v[15];  // column 31, for the next chunk (this wave's own: no barrier)
+      if (!PAIR && g == 1) lds.carry[qA][mt][xl_] = v[15];  // column 31, for the next chunk (this wave's own: no barrier)
     };
     if (a.Wc - 32 * ck <= 16) {                                // (uniform)
       for (int q = q0; q < kCR; q += 4) rows(q, q + 2, std::true_type{});

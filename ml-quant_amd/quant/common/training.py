@@ -27,6 +27,31 @@ logger = logging.getLogger(__name__)
 Hook = Callable[..., None]
 
 
+def _stem_flag(device) -> bool:
+    """Is THIS rank's device flag of the fused stem up (an operand outside the fp16 split's domain since the last reset)?"""
+    if torch.device(device).type != 'cuda':
+        return False
+    from quant import _hip
+    return bool(_hip.available() and _hip.stem_overflow_flag_raised(device))
+
+
+def _stem_flag_reset(device) -> None:
+    if torch.device(device).type == 'cuda':
+        from quant import _hip
+        _hip.stem_overflow_reset(device, keep_tripped=True)
+
+
+def _any_rank(flag: bool, device, sharded: bool) -> bool:
+    """``flag`` or-ed over the ranks of a sharded evaluation: the flag is per device, so only the rank whose shard held the
+    offending sample sees it -- and a rank that repeated the pass alone would issue a second series of all-gathers that the
+    others never join.  Every rank calls this at the same point; all get the same answer."""
+    if not sharded:
+        return flag
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: torch.device, epoch: int,
              hooks: Optional[Sequence[Hook]] = None, _retry: bool = False) -> Dict[str, float]:
     """Evaluate ``model`` on ``test_loader``; returns {metric name: value}."""
@@ -35,6 +60,10 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
     for metric in metrics.values():
         metric.reset()
     sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not _retry and _stem_flag(device):
+        # the flag is sticky and shared by everything that runs on this device: one raised BEFORE this pass (an earlier
+        # forward, another model) is noted and lowered, so that only overflows of THIS pass make it repeat
+        _stem_flag_reset(device)
     batch_idx = -1
     # consecutive batches alternate between two HIP streams (stream_pipeline.py: the dispatch ramp and the last tiles of one
     # forward's kernels run under the other forward's kernels); the metrics of batch i - 1 -- and, when the batch is sharded
@@ -63,17 +92,17 @@ def evaluate(model: nn.Module, test_loader, metrics: Dict[str, Metric], device: 
                 consume()
         while window:
             consume()
-    if torch.device(device).type == 'cuda':
-        from quant import _hip
-        if _hip.available() and _hip.stem_overflow_flag_raised(device):
-            # batches of this pass were computed on saturated stem operands (inf / nan logits): the stem has switched to the
-            # bf16 split, which takes any finite input -- the whole pass is repeated on it instead of reporting those metrics
+    if torch.device(device).type == 'cuda' or sharded:
+        # batches of this pass computed on saturated stem operands (inf / nan logits) on ANY rank: the stem has switched to
+        # the bf16 split, which takes any finite input -- the whole pass is repeated on it, by every rank or by none
+        if _any_rank(_stem_flag(device), device, sharded):
             if not _retry:
                 logger.warning('lsq_stem_conv_pool saw operands at or beyond 65504 during this evaluation; repeating it with '
                                'the bf16 split of the stem')
-                _hip.stem_overflow_reset(device, keep_tripped=True)
+                _stem_flag_reset(device)
                 return evaluate(model, test_loader, metrics, device, epoch, hooks, _retry=True)
-            logger.warning('lsq_stem_conv_pool: the flag is still raised after the repeated evaluation (non-finite input?)')
+            logger.error('lsq_stem_conv_pool: the flag is still raised after the repeated evaluation (another model on this '
+                         'device?); the metrics below may come from saturated logits')
     for hook in hooks:
         hook(epoch=epoch, global_step=1 + (epoch - 1) * len(test_loader.dataset) + batch_idx)
     computed = {name: metric.compute() for name, metric in metrics.items()}

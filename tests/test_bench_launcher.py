@@ -71,6 +71,10 @@ def test_bench_starts_its_own_ranks():
     assert out['allgather']['world_size_seen_by_backend'] == 2 and out['allgather']['bytes_received_per_rank'] == 2 * 1000 * 4
     assert out['device'] == 'cpu' and 'PLUMBING' in out['note'] and 'roofline' not in out and 'cpu_baseline' not in out
     assert out['value'] > 0 and out['steps_timed'] == 2
+    # 8-GPU readiness: rank 0's line at N > 1 carries the exchange's per-link rate and both issue orders
+    assert out['allgather']['per_link_GBps'] > 0 and out['allgather']['backend'] == 'gloo'
+    assert out['pipelined']['value'] == out['value'] and out['pipelined']['vs_single_stream'] > 0
+    assert out['single_stream']['value'] > 0 and out['single_stream']['steps_timed'] >= 2 and 'value_definition' in out
 
 
 def test_bench_under_torchrun_and_with_a_world_size_that_differs_from_gpus():

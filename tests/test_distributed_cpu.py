@@ -154,3 +154,57 @@ def test_sharded_evaluate_with_a_batch_smaller_than_the_world(tmp_path):
     for r in range(world):
         d = torch.load(os.path.join(str(tmp_path), f's{r}.pt'))
         assert abs(float(d['metric']) - d['want']) < 1e-6 or abs(float(d['metric']) - 100 * d['want']) < 1e-4, d
+
+
+def _worker_overflow_flag(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'ml-quant_amd'), os.path.join(ROOT, 'tests', 'golden')):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import detgen
+    from quant.common import training
+    from quant.common.metrics import Top1Accuracy
+    torch.set_num_threads(2)
+    model = _tiny_resnet()
+    xs = detgen.normal('dist.flag', (8, 3, 16, 16))
+    ys = torch.arange(8) % 10
+
+    class Loader(list):
+        dataset = list(range(8))
+    loader = Loader([(xs[:4], ys[:4]), (xs[4:], ys[4:])])
+    # the stem's device flag as ONE rank would see it: up after the first pass on rank 1 only, down after the reset
+    state = {'raised': False, 'asked': 0, 'resets': 0, 'passes': 0}
+
+    def flag(device):
+        state['asked'] += 1
+        return state['raised']
+
+    def reset(device):
+        state['resets'] += 1
+        state['raised'] = False
+    training._stem_flag, training._stem_flag_reset = flag, reset
+    local_forward = training.local_forward
+
+    def counting_forward(m, shard):
+        state['passes'] += 1
+        if rank == 1 and state['passes'] == 1:
+            state['raised'] = True                    # "the kernel saw an operand beyond 65504" in rank 1's first batch
+        return local_forward(m, shard)
+    training.local_forward = counting_forward
+    out = training.evaluate(model, loader, {'Top-1 Accuracy': Top1Accuracy(accumulate=True)}, torch.device('cpu'), epoch=1)
+    torch.save({'metric': out['Top-1 Accuracy'], 'state': state}, os.path.join(out_dir, f'f{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluate_repeats_on_every_rank_when_one_rank_saw_an_overflow(tmp_path):
+    """the stem's out-of-domain flag is per device.  When only ONE rank's shard held the offending sample,
+    that rank alone used to re-enter evaluate() and issue a second series of all-gathers -- a hang.  The decision is now
+    all-reduced: both ranks run the pass twice (4 forwards each: 2 batches x 2 passes) and report the same metric."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_overflow_flag, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ds = [torch.load(os.path.join(str(tmp_path), f'f{r}.pt')) for r in range(world)]
+    assert ds[0]['state']['passes'] == ds[1]['state']['passes'] == 4, [d['state'] for d in ds]
+    assert ds[0]['state']['resets'] == ds[1]['state']['resets'] == 1
+    assert float(ds[0]['metric']) == float(ds[1]['metric'])

@@ -235,9 +235,17 @@ def test_full_size_whole_network(act):
             wq = conv.w_approximate.v1.view(-1, 1, 1, 1) * P.pm1(conv.weight)
             ref = torch.nn.functional.conv2d(xq.double(), wq.double(), conv.bias.double(), conv.stride, 1).float()
             assert rel_err(yout, ref) <= TOL, (li, rel_err(yout, ref))
-        # fused blocks (the batch run) and the module-by-module path agree on the same rows
-        cos = torch.nn.functional.cosine_similarity(ym.flatten(), y1[rows].flatten(), dim=0)
-        assert 1.0 - float(cos) <= 1e-3
+        # fused blocks (the batch run) against the module-by-module path on the same rows: the two fold the batch norm
+        # differently (one fma in the quantizer's read against torch's batch norm), i.e. they differ by arithmetic noise that
+        # the solve's near-ties amplify -- the limit is the derived one for two runs of one solver (free_limits.json,
+        # `resnet_logits_cos`: 1.05 x the tie-break's effect + 2 x the network's sensitivity, tests/golden/make_free_limits.py),
+        # in fp64; the fused path's OWN layers are checked to 1e-4 in tests/test_gpu_round6.py::test_full_size_fused_network_every_layer
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'free_limits.json')) as f:
+            limit = json.load(f)['limits']['resnet_logits_cos']['limit']
+        cos = torch.nn.functional.cosine_similarity(ym.double().flatten(), y1[rows].double().flatten(), dim=0)
+        assert 1.0 - float(cos) <= limit, (float(cos), limit)
 
 
 @pytest.mark.parametrize('c, h, o, stride', [(64, 56, 64, 1), (64, 56, 128, 2), (128, 28, 128, 1), (128, 28, 256, 2),

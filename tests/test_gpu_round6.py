@@ -220,3 +220,82 @@ def test_three_stream_tensor_leaving_the_fused_path_is_unpacked():
         finally:
             resnet.FUSE_BLOCKS = True
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- the path bench.py times, layer by layer
+@pytest.mark.parametrize('act', ['ls-2', 'ls-T'])
+def test_full_size_fused_network_every_layer(act):
+    """The FUSED batch-256 forward -- what bench.py times -- checked layer by layer on three rows of the batch (round 5's
+    test_full_size_whole_network does this on the module-by-module path and compared the two paths by a hand-set cosine):
+    every QuantConv2d.fused_forward call is recorded in place, and for each of the 16 layers
+      * the solved v1 equals the exact oracle on the very tensor the layer quantized (the eval batch norm folded as ONE fma
+        per element, as the kernel's read does),
+      * the layer's output is within north_star's 1e-4 of max|y| of an fp64 convolution of that quantized input with the
+        GPU's own scales, the block's epilogue (residual before / after the non-linearity, ReLU or PReLU) included."""
+    import bench
+    from oracle import ref_port as P
+    from quant.binary.binary_conv import QuantConv2d
+    model = bench.build_model(bench.imagenet_arch(act, 3 if act == 'ls-2' else 2), DEV)
+    x = torch.randn(256, 3, 224, 224, generator=torch.Generator().manual_seed(0)).to(DEV)
+    rows = [0, 131, 255]
+    seen = []
+    orig = QuantConv2d.fused_forward
+
+    def spy(self, xin, pre_bn=None, relu=False, res_pre=None, res_post=None, prelu=None, next_q=None, res_ready=None):
+        out = orig(self, xin, pre_bn, relu, res_pre, res_post, prelu, next_q, res_ready)
+        pick = lambda t: None if t is None else t[rows].clone()        # noqa: E731
+        seen.append((self, pre_bn, relu, None if prelu is None else prelu.detach().clone(), pick(xin), pick(res_pre), pick(res_post),
+                     pick(out), self.last_act_scales[:, rows].clone()))
+        return out
+    QuantConv2d.fused_forward = spy
+    try:
+        with torch.no_grad():
+            model(x)
+    finally:
+        QuantConv2d.fused_forward = orig
+    assert len(seen) == 16
+    ternary = act == 'ls-T'
+    for li, (conv, bn, relu, slope, xin, rpre, rpost, yout, scales) in enumerate(seen):
+        alpha = conv._alpha()
+        s, t = conv._folded_bn(bn)
+        xb = (xin.double() * s.double().view(1, -1, 1, 1) + t.double().view(1, -1, 1, 1)).float()     # one rounding: the kernel's fma
+        xc = xb.clamp(-alpha, alpha)
+        want = E.solve_rows(xc.reshape(len(rows), -1).cpu().numpy(), ternary, 3)
+        assert np.array_equal(scales[0].cpu().numpy(), want), (li, scales[0], want)
+        xq = P.quant_lst(xc, scales[0])[1] if ternary else P.quant_ls2(xc, scales[0], scales[1])[2]
+        wq = conv.w_approximate.v1.view(-1, 1, 1, 1) * P.pm1(conv.weight)
+        ref = torch.nn.functional.conv2d(xq.double(), wq.double(), conv.bias.double(), conv.stride, 1)
+        if rpre is not None:
+            ref = ref + rpre.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        if slope is not None:
+            ref = torch.where(ref > 0, ref, ref * slope.double().view(1, -1, 1, 1))
+        if rpost is not None:
+            ref = ref + rpost.double()
+        err = float((yout.double() - ref).abs().max() / ref.abs().max())
+        assert err <= 1e-4, (li, err)
+
+
+def test_non_finite_rows_stay_contained_in_the_windowed_solve():
+    """a row with NaN / +-Inf activations under a symmetric clamp (Inf clamps to alpha, a NaN to -alpha: the
+    windowed histogram's index stays inside its 8192 bins -- now also bounded explicitly) must neither fault nor touch its
+    neighbours: the finite rows of the batch come out exactly as they do alone, and the Inf row as its clamped self."""
+    rs = np.random.RandomState(8)
+    for (c, h) in [(64, 56), (128, 28), (512, 7)]:
+        x = torch.from_numpy((rs.standard_normal((4, c, h, h)) * 1.5).astype(np.float32))
+        bad = x.clone()
+        bad[1].view(-1)[::7] = float('nan')
+        bad[1].view(-1)[3::11] = float('inf')
+        bad[2].view(-1)[5::13] = float('-inf')              # no NaN in row 2: it equals its clamped self
+        for ternary in (False, True):
+            p_bad, s_bad = _quantize(bad, 3.0, ternary)
+            p_ok, s_ok = _quantize(x, 3.0, ternary)
+            p_cl, s_cl = _quantize(bad.clamp(-3, 3).nan_to_num(0.0), 3.0, ternary)
+            words = p_ok.numel() // 2 // 4
+            for row in (0, 3):
+                assert s_bad[0, row] == s_ok[0, row] and s_bad[1, row] == s_ok[1, row], (c, h, ternary, row)
+                for plane in (0, 1):
+                    a = p_bad.view(2, 4, words)[plane, row]
+                    assert torch.equal(a, p_ok.view(2, 4, words)[plane, row]), (c, h, ternary, row, plane)
+            assert s_bad[0, 2] == s_cl[0, 2] and torch.equal(p_bad.view(2, 4, words)[:, 2], p_cl.view(2, 4, words)[:, 2])
