@@ -662,7 +662,7 @@ def main():
                     'popc', model, x, 40, 5, 'the headline network with every XNOR convolution on the popcount kernel '
                     '(v_xor + v_bcnt, csrc/lsq_xnor_conv.hip) instead of the int8-MFMA kernel: same bits out')
             finally:
-                _hip.xnor_impl(bool(old))
+                _hip.xnor_impl(int(old))
             del model
             m = build_model(imagenet_arch('fp', 2), device)
             cfg['imagenet_ls1w_fpa_b256'] = config_leg('fp', m, x, 40, 5, 'ResNet-18 ImageNet ls-1 weight / fp activation '

@@ -20,8 +20,9 @@
 extern "C" {
 #endif
 
-/* 1: lsq_xnor_conv2d takes the popcount kernel for every geometry (default 0: integer-MFMA kernel where it applies) */
-int lsq_debug_xnor_impl(int popcount_only);
+/* lsq_xnor_conv2d: 0 (default) the matrix-core kernel where it applies -- fp4 operands on v_mfma_scale_f32_32x32x64_f8f6f4 --,
+ * 1 the popcount kernel for every geometry, 2 the int8 matrix-core kernel of rounds 2-5; all three give the same bits */
+int lsq_debug_xnor_impl(int impl);
 /* 1: lsq_act_quant / lsq_solve_rows take the streaming three-kernel path for every shape (default 0) */
 int lsq_debug_force_streaming(int on);
 /* single-launch quantizer, bit mask (default 0): 1 = every flagged bin of the round-2 solve through its block path, 2 = its

@@ -27,6 +27,7 @@ struct ConvArgs {
   int res_stream;                      // the residual operand is read with the non-temporal hint: it and the output together exceed the
                                        // Infinity Cache and this is its last use (set by the entry point, kStreamBytes)
   int dbg_no_corr;                     // tuning builds only
+  int int8_mfma;                       // test hook: the int8 matrix-core kernel instead of the fp4 one (two-plane, unchained launches)
   // ---- three-stream rows (LSQ_LAYOUT_SPLIT3, include/lsq_hip.h): 0 = NCHW, else S = floats per stream of the tensor's rows
   int y_s3;                            // layout of y (and of the partial sums read back with `accumulate`)
   int res_s3;                          // layout of res_pre / res_post (both)

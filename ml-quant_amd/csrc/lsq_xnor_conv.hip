@@ -248,7 +248,7 @@ using namespace lsq;
 
 // test hook (include/lsq_hip_debug.h, not part of the product ABI): 1 = every geometry through the popcount kernel
 static std::atomic<int> g_force_popcount{0};
-extern "C" int lsq_debug_xnor_impl(int popcount_only) { return g_force_popcount.exchange(popcount_only, std::memory_order_relaxed); }
+extern "C" int lsq_debug_xnor_impl(int impl) { return g_force_popcount.exchange(impl, std::memory_order_relaxed); }
 
 static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscales, const uint64_t* wbits,
                             const int32_t* wsum, int kw_planes, const float* wscales, const float* bias,
@@ -292,7 +292,7 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
   if (layouts) {
     // three-stream rows (include/lsq_hip.h): the integer-MFMA kernel only
     const int64_t S = lsq_split3_stream_floats(g->O, Ho, Wo);
-    if (S <= 0 || 3 * S * g->N >= (1ll << 31) || g_force_popcount.load(std::memory_order_relaxed) || x_units || next) return LSQ_E_UNSUPPORTED;
+    if (S <= 0 || 3 * S * g->N >= (1ll << 31) || g_force_popcount.load(std::memory_order_relaxed) == 1 || x_units || next) return LSQ_E_UNSUPPORTED;
     a.s3_hp = (int)(S / g->O);
     a.y_s3 = y_layout == LSQ_LAYOUT_SPLIT3 ? (int)S : 0;
     a.res_s3 = res_layout == LSQ_LAYOUT_SPLIT3 ? (int)S : 0;
@@ -341,7 +341,9 @@ static int xnor_conv2d_impl(const uint64_t* xplanes, int kx, const float* xscale
       a.wscale = wscales + (long long)q * g->O;
       a.accumulate = first ? 0 : 1;
       a.final_pass = (q == kw_planes - 1 && p0 + np >= kx) ? 1 : 0;
-      int e = (g_force_popcount.load(std::memory_order_relaxed) && !chained) ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
+      const int impl = g_force_popcount.load(std::memory_order_relaxed);      // 0: matrix cores (fp4), 1: popcount kernel, 2: matrix cores (int8)
+      a.int8_mfma = impl == 2;
+      int e = (impl == 1 && !chained) ? kXnorMfmaNotEligible : xnor_conv_mfma(a, np, g->groups, st);
       if (e == kXnorMfmaNoLayout || (e == kXnorMfmaNotEligible && (chained || layouts))) return LSQ_E_UNSUPPORTED;
       if (e == kXnorMfmaNotEligible) e = np == 2 ? launch_kx<2>(a, g->groups, st) : launch_kx<1>(a, g->groups, st);
       if (e) return e;
@@ -388,7 +390,7 @@ extern "C" int lsq_layout_support(const lsq_conv_geom* g, int scheme, int kx) {
   const int Ho = out_h(g), Wo = out_w(g);
   if (g->groups == 1 && g->KH == 3 && g->KW == 3 && g->dil_w == 1 && g->O % 32 == 0 && kx == 2 && (cg == 64 || cg == 128) &&
       Ho > 0 && Wo > 0 && lsq_split3_stream_floats(g->O, Ho, Wo) > 0 && 3 * lsq_split3_stream_floats(g->O, Ho, Wo) * g->N < (1ll << 30) &&
-      !g_force_popcount.load(std::memory_order_relaxed))
+      g_force_popcount.load(std::memory_order_relaxed) != 1)
     mask |= 2 | 4;
   return mask;
 }

@@ -26,6 +26,8 @@
 // Tile = 32 consecutive output pixels (flat over n, ho, wo) x 32 out-channels per wave; D[o][pixel]: a lane holds
 // ONE pixel (column lane & 31) and 16 out-channels (rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
 
+#include <type_traits>
+
 #include "lsq_xnor_conv.h"
 #ifndef LSQ_Y3_WAVES
 #define LSQ_Y3_WAVES 12
@@ -36,6 +38,8 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr unsigned kM0 = 0x01010101u;
 
@@ -60,12 +64,22 @@ constexpr unsigned kM0 = 0x01010101u;
 // workgroup at the same time (wave = (slot, j), NWAVES = 6: two groups per workgroup and round) and meet in the CU's L1; on
 // three different CUs (the first version) the planes went through the L2s 2.8 times and the 56 x 56 layers took 141 us
 // against 92.  Residual operands may have either layout.
-template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN, bool YS3, bool RS3>
+//
+// FP4 (round 6): the same kernel on v_mfma_scale_f32_32x32x64_f8f6f4 with both operands in fp4 (E2M1) and unit block scales --
+// the matrix cores' fastest format, twice the int8 rate (MI355X_MICROARCH.md: 9.1 PF measured against 4.4 POP/s), and
+// still EXACT here: a sign bit of the packed word becomes an fp4 code with ONE v_and_b32 per EIGHT channels -- nibble j of
+// register q of a lane is channel q + 4 j of its dword, `d & (0x11111111 << q)` holds codes 1 / 2 / 4 = 0.5 / 1 / 2 (q = 3 would
+// be the sign bit: that register is `(d >> 3) & 0x11111111`, 0.5 again) --, the weight nibble of the same slot is +-(4, 2, 1,
+// 4), so every product is +-2 or 0 and the fp32 accumulator, started at the border term fc, IS (b * s): integers below 2^13,
+// exact in any order.  Half the operand-build instructions, half the MFMAs and half the LDS bytes per binary MAC;
+// scripts/ubench/fp4_mfma_check.hip is the known-answer test of the instruction (subnormal code 1 = 0.5 included).
+template <int KX, int GG, int TAPS, int NWAVES, int WPC, bool CHAIN, bool YS3, bool RS3, bool FP4>
 __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a) {
   constexpr bool S3 = YS3 || RS3;                // (which operands have the three-stream layout is fixed per instantiation:
                                                  //  runtime selects between two sets of sixteen channel offsets cost scalar registers)
   constexpr int NT = 64 * NWAVES;
-  constexpr int NF = TAPS * GG * 2;              // 16-byte operand fragments per lane: (word, tap, half of the dword's bits)
+  constexpr int FPS = FP4 ? 1 : 2;               // 16-byte weight fragments per (word, tap) step: int8 K = 32 twice, fp4 K = 64 once
+  constexpr int NF = TAPS * GG * FPS;            // 16-byte operand fragments per lane
   constexpr int NW = TAPS * KX;                  // activation dwords per lane and group (= one channel word of a tile)
   __shared__ v4i s_w[NF][64];
   __shared__ int s_ws[TAPS][32];
@@ -255,6 +269,17 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       entry(e, L, tj, pos);
       const unsigned long long w = wword[k];
       const unsigned d = (pos & 1) ? (unsigned)(w >> 32) : (unsigned)w;
+      if constexpr (FP4) {
+        // nibble j of register q = channel q + 4 j: +-(4, 2, 1, 4) as E2M1 codes 6 / 4 / 2 / 6, sign bit 8 where the weight is -1
+        v4i out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned mag = (q == 1 ? 0x4u : (q == 2 ? 0x2u : 0x6u)) * 0x11111111u;
+          const unsigned ones = (d >> q) & 0x11111111u;
+          out[q] = (int)(mag | ((ones ^ 0x11111111u) << 3));
+        }
+        s_w[tj][L] = out;
+      } else {
       v4i out[2];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -266,6 +291,7 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
       }
       s_w[2 * tj][L] = out[0];
       s_w[2 * tj + 1][L] = out[1];
+      }
     }
   }
 #pragma unroll
@@ -299,12 +325,13 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 
   // ---- tiles ------------------------------------------------------------------------------------------------------
   constexpr int kRing = 3;                       // weight fragments of kRing consecutive (word, tap) steps; 9 GG % kRing == 0
-  v4i wring[kRing][2];
+  v4i wring[kRing][FPS];
 #pragma unroll
   for (int i = 0; i < kRing - 1; ++i) {
-    wring[i][0] = s_w[2 * i][lane];
-    wring[i][1] = s_w[2 * i + 1][lane];
+#pragma unroll
+    for (int f = 0; f < FPS; ++f) wring[i][f] = s_w[FPS * i + f][lane];
   }
+  const int unit_scale = 0x7F7F7F7F;             // E8M0 127 = 2^0 in every byte (fp4: the block scales of both operands)
 #ifdef LSQ_XNOR_CLOCKS
   long long clk[15];
   int nclk = 0;
@@ -335,10 +362,12 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
     lay_of(pixv, ln, y_s3, ly);
     lay_of(pixv, ln, r_s3, lr);
     float xs[KX], rv[16], basev[16];
+    // (int8: the accumulators hold 32 (b * s), hence xs / 32 -- exact; fp4: they hold (b * s) itself)
+    constexpr float kAccUnit = FP4 ? 1.0f : 0.03125f;
 #pragma unroll
-    for (int p = 0; p < KX; ++p) xs[p] = (!CHAIN || a.xscales) ? a.xscales[p * a.N + ln] * 0.03125f : 0.f;
+    for (int p = 0; p < KX; ++p) xs[p] = (!CHAIN || a.xscales) ? a.xscales[p * a.N + ln] * kAccUnit : 0.f;
     if (CHAIN && a.xunits)          // chained ls-1 layer: the scale is the exact row sum the producer's epilogue left, / M as the sweeps do
-      xs[0] = (float)(((double)a.xunits[ln] * a.xunit) / a.xM) * 0.03125f;
+      xs[0] = (float)(((double)a.xunits[ln] * a.xunit) / a.xM) * kAccUnit;
     if (want_pre || want_post) {
       const float* __restrict__ rsrc = want_pre ? a.res_pre : a.res_post;
       if (a.res_stream) {           // (uniform) last use of a tensor that does not fit the Infinity Cache next to the output: lsq_xnor_conv.h
@@ -363,7 +392,8 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
 
     // The accumulators start at 32 * fc (fc = what the pixel's border pattern adds to 2 * the matrix-core sum, from
     // the table): the matrix core does the epilogue's integer additions, and 64 * S + 32 * fc = 32 * (b * s).
-    v16i acc[KX];
+    typedef typename std::conditional<FP4, v16f, v16i>::type acc_t;
+    acc_t acc[KX];
     {
       const int hi0 = cur.ho * a.sh - a.ph, wi0 = cur.wo * a.sw - a.pw;
       unsigned bad_h = 0, bad_w = 0;
@@ -379,10 +409,17 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
         const short4 f4 = *reinterpret_cast<const short4*>(fcp + 8 * g);
 #pragma unroll
         for (int p = 0; p < KX; ++p) {
-          acc[p][4 * g + 0] = (int)f4.x << 5;
-          acc[p][4 * g + 1] = (int)f4.y << 5;
-          acc[p][4 * g + 2] = (int)f4.z << 5;
-          acc[p][4 * g + 3] = (int)f4.w << 5;
+          if constexpr (FP4) {
+            acc[p][4 * g + 0] = (float)f4.x;
+            acc[p][4 * g + 1] = (float)f4.y;
+            acc[p][4 * g + 2] = (float)f4.z;
+            acc[p][4 * g + 3] = (float)f4.w;
+          } else {
+            acc[p][4 * g + 0] = (int)f4.x << 5;
+            acc[p][4 * g + 1] = (int)f4.y << 5;
+            acc[p][4 * g + 2] = (int)f4.z << 5;
+            acc[p][4 * g + 3] = (int)f4.w << 5;
+          }
         }
       }
     }
@@ -404,27 +441,46 @@ __global__ __launch_bounds__(64 * NWAVES, WPC) void xnor_mfma_kernel(ConvArgs a)
         constexpr int kAll = GG * TAPS;
         const int idx = j * TAPS + t;
         const int pre = (idx + kRing - 1) % kAll;
-        wring[(idx + kRing - 1) % kRing][0] = s_w[2 * pre][wl];
-        wring[(idx + kRing - 1) % kRing][1] = s_w[2 * pre + 1][wl];
+#pragma unroll
+        for (int f = 0; f < FPS; ++f) wring[(idx + kRing - 1) % kRing][f] = s_w[FPS * pre + f][wl];
         __builtin_amdgcn_sched_barrier(0);         // reads first: they must not sink below this step's MFMAs
-        const v4i w0 = wring[idx % kRing][0], w1 = wring[idx % kRing][1];
-        v4i b0[KX], b1[KX];
+        if constexpr (FP4) {
+          const v4i w4 = wring[idx % kRing][0];
+          const v8i w8 = {w4[0], w4[1], w4[2], w4[3], 0, 0, 0, 0};      // (fp4 operands: the low four registers are read)
+          v8i b8[KX];
 #pragma unroll
-        for (int p = 0; p < KX; ++p) {
-          const unsigned d = xc[t * KX + p];
-          b0[p][0] = (int)(d & kM0);
-          b0[p][1] = (int)(d & (kM0 << 1));
-          b0[p][2] = (int)(d & (kM0 << 2));
-          b0[p][3] = (int)(d & (kM0 << 3));
-          b1[p][0] = (int)(d & (kM0 << 4));
-          b1[p][1] = (int)(d & (kM0 << 5));
-          b1[p][2] = (int)(d & (kM0 << 6));
-          b1[p][3] = (int)((d >> 7) & kM0);
+          for (int p = 0; p < KX; ++p) {
+            const unsigned d = xc[t * KX + p];
+            b8[p] = v8i{(int)(d & 0x11111111u), (int)(d & 0x22222222u), (int)(d & 0x44444444u), (int)((d >> 3) & 0x11111111u), 0, 0, 0, 0};
+          }
+#pragma unroll
+          for (int p = 0; p < KX; ++p)
+            acc[p] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, b8[p], acc[p], 4, 4, 0, unit_scale, 0, unit_scale);
+          // (the scaled MFMA is a pure value to the instruction selector, which -- unlike with the int8 builtin -- gathered all of a
+          //  tile's fragment reads in front of the first one and spilled them; an empty asm on the accumulators ties each step
+          //  to its place between the scheduling barriers)
+#pragma unroll
+          for (int p = 0; p < KX; ++p) asm volatile("" : "+v"(acc[p]));
+        } else {
+          const v4i w0 = wring[idx % kRing][0], w1 = wring[idx % kRing][FPS - 1];
+          v4i b0[KX], b1[KX];
+#pragma unroll
+          for (int p = 0; p < KX; ++p) {
+            const unsigned d = xc[t * KX + p];
+            b0[p][0] = (int)(d & kM0);
+            b0[p][1] = (int)(d & (kM0 << 1));
+            b0[p][2] = (int)(d & (kM0 << 2));
+            b0[p][3] = (int)(d & (kM0 << 3));
+            b1[p][0] = (int)(d & (kM0 << 4));
+            b1[p][1] = (int)(d & (kM0 << 5));
+            b1[p][2] = (int)(d & (kM0 << 6));
+            b1[p][3] = (int)((d >> 7) & kM0);
+          }
+#pragma unroll
+          for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0[p], acc[p], 0, 0, 0);
+#pragma unroll
+          for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1[p], acc[p], 0, 0, 0);
         }
-#pragma unroll
-        for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w0, b0[p], acc[p], 0, 0, 0);
-#pragma unroll
-        for (int p = 0; p < KX; ++p) acc[p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, b1[p], acc[p], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (j + 1 < GG || more) {
@@ -580,8 +636,8 @@ int launch_y3(const ConvArgs& a, hipStream_t st) {
   if (gx * kSlots > ngroups) gx = (ngroups + kSlots - 1) / kSlots;
   gx = gx < 1 ? 1 : gx;
   const dim3 grid((unsigned)gx, (unsigned)n_ot), block(64 * NWAVES);
-  if (a.res_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, true>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, false>), grid, block, 0, st, a);
+  if (a.res_s3) hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, true, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, true, false, true>), grid, block, 0, st, a);
   return (int)hipGetLastError();
 }
 
@@ -606,16 +662,19 @@ int launch(const ConvArgs& a, hipStream_t st) {
     // of a wave to be a multiple of 3
     if constexpr (KX == 2 && GG <= 2) {
       if (a.y_s3) return launch_y3<KX, GG>(a, st);
-      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, true, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
       return (int)hipGetLastError();
     } else {
       return kXnorMfmaNoLayout;
     }
   }
   if (KX == 1 && (a.xunits || a.nq_planes32))
-    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   else
-    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+    if (a.int8_mfma)          // (test hook lsq_debug_xnor_impl(2): round 2-5's int8 kernel, the fp4 kernel's comparator -- same bits)
+      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+    else
+      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
   return (int)hipGetLastError();
 }
 

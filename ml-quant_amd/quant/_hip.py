@@ -645,10 +645,11 @@ def ste_backward(x: torch.Tensor, grad_q: torch.Tensor, scales: Optional[torch.T
     return out
 
 
-def xnor_impl(popcount_only: bool) -> int:
-    """Test / profiling hook (include/lsq_hip_debug.h): route every XNOR convolution through the popcount kernel (True)
-    or let the dispatcher pick the integer-MFMA kernel where it applies (False, the default).  Returns the old value."""
-    return lib().lsq_debug_xnor_impl(int(bool(popcount_only)))
+def xnor_impl(mode) -> int:
+    """Test / profiling hook (include/lsq_hip_debug.h): 1 / True = every XNOR convolution through the popcount kernel, 0 / False
+    = the dispatcher picks the matrix-core kernel where it applies (fp4 operands on the scaled MFMA, the default), 2 = the
+    same with the int8 matrix-core kernel of rounds 2-5 (identical results).  Returns the old value."""
+    return lib().lsq_debug_xnor_impl(int(mode))
 
 
 @contextlib.contextmanager
@@ -673,7 +674,7 @@ def debug_switches(xnor_popcount: Optional[bool] = None, force_streaming: Option
     old = {}
     try:
         if xnor_popcount is not None:
-            old['lsq_debug_xnor_impl'] = handle.lsq_debug_xnor_impl(int(bool(xnor_popcount)))
+            old['lsq_debug_xnor_impl'] = handle.lsq_debug_xnor_impl(int(xnor_popcount))
         if force_streaming is not None:
             old['lsq_debug_force_streaming'] = handle.lsq_debug_force_streaming(int(bool(force_streaming)))
         if fused_mode is not None:

@@ -931,7 +931,8 @@ def test_pointwise_conv_kernel(n, c, h, w, o, stride):
 
 @pytest.mark.parametrize('xs, ws', [('ls-2', 'ls-1'), ('ls-1', 'ls-1'), ('ls-2', 'gf-2'), ('ls-T', 'ls-1')])
 def test_xnor_mfma_kernel_equals_popcount_kernel(xs, ws):
-    """The integer-MFMA implementation of the binary 3x3 convolution over 64 / 128 / 256 / 512 channels against the popcount kernel:
+    """The matrix-core implementations of the binary 3x3 convolution over 64 / 128 / 256 / 512 channels -- fp4 operands on the scaled
+    MFMA (round 6, the default) and int8 operands (rounds 2-5, lsq_debug_xnor_impl(2)) -- against the popcount kernel:
     same operands, same epilogue arithmetic on the same exact integers -> the same floats, bit for bit.  Strides,
     paddings (halo correction on every side), dilation, pixel counts that are not multiples of the 32-pixel tile,
     several out-channel tiles, several weight planes (accumulating launches), the fused block epilogue."""
@@ -952,7 +953,7 @@ def test_xnor_mfma_kernel_equals_popcount_kernel(xs, ws):
             conv(x.cpu())                                    # caches the weight scales
         conv.eval().to(DEV)
         outs = []
-        for popcount_only in (True, False):
+        for popcount_only in (True, False, 2):               # popcount kernel, fp4 matrix-core kernel (the default), int8 matrix-core kernel
             with hip.debug_switches(xnor_popcount=popcount_only), torch.no_grad():
                 y = conv(x)
                 res = detgen.normal(tag + '.res', tuple(y.shape), scale=0.8).to(DEV)
@@ -960,8 +961,9 @@ def test_xnor_mfma_kernel_equals_popcount_kernel(xs, ws):
                 y2 = conv.fused_forward(x, None, True, None, res)
                 y3 = conv.fused_forward(x, None, False, res, res)
             outs.append((y, y1, y2, y3))
-        for u, v in zip(*outs):
-            assert torch.equal(u, v), (xs, ws, ci, float((u - v).abs().max()))
+        for impl in (1, 2):
+            for u, v in zip(outs[0], outs[impl]):
+                assert torch.equal(u, v), (xs, ws, ci, impl, float((u - v).abs().max()))
 
 
 def test_xnor_mfma_kernel_random_geometries():
@@ -991,13 +993,14 @@ def test_xnor_mfma_kernel_random_geometries():
         conv.eval().to(DEV)
         x = detgen.normal(f'gpu.xmr.{done}', (n, cin, h, w), scale=1.2).to(DEV)
         outs = []
-        for popcount_only in (True, False):
+        for popcount_only in (True, False, 2):               # popcount kernel, fp4 matrix-core kernel (the default), int8 matrix-core kernel
             with hip.debug_switches(xnor_popcount=popcount_only), torch.no_grad():
                 y = conv(x)
                 res = torch.sin(torch.arange(y.numel(), device=DEV, dtype=torch.float32)).view_as(y)
                 outs.append((y, conv.fused_forward(x, None, True, None, res)))
-        for u, v in zip(*outs):
-            assert torch.equal(u, v), ((n, cin, h, w), cout, stride, pad, dil, xs, float((u - v).abs().max()))
+        for impl in (1, 2):
+            for u, v in zip(outs[0], outs[impl]):
+                assert torch.equal(u, v), ((n, cin, h, w), cout, stride, pad, dil, xs, impl, float((u - v).abs().max()))
 
 
 def test_random_conv_geometries_against_oracle():
