@@ -138,6 +138,7 @@ def build_lenet(device):
 
 
 MFMA_I8_PEAK_T = 5000.0      # TOP/s dense int8 = 2 x the bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_FP4_PEAK_T = 10000.0    # TOP/s dense fp4 / fp6 (block-scaled MFMA, MI355X_MICROARCH.md: ~10 PF dense, 9099 TF measured)
 POPCOUNT_PEAK_T = 1258.0      # 256 CU x 128 lanes x 2.4 GHz, v_xor + v_bcnt per 32 binary MACs
 HBM_PEAK_GBPS = 8000.0
 MFMA_BF16_PEAK_T = 2500.0
@@ -181,12 +182,15 @@ def kernel_roofline(name, launches, ms, nbytes, ops, survey_bytes=None, shapes=N
         hbm['achieved_survey_8d'] = survey_bytes / sec / 1e9
         hbm['frac_survey_8d'] = survey_bytes / sec / 1e9 / HBM_PEAK_GBPS
     if name == 'lsq_xnor_conv2d':
-        # 3x3 layers over 64..512 channels run on v_mfma_i32_32x32x32_i8 (csrc/lsq_xnor_mfma.hip): integer MFMA bound,
-        # 2 ops per binary MAC; the popcount kernel (other geometries) is priced against the same peak
+        # 3x3 layers over 64..512 channels run on v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 operands (csrc/lsq_xnor_mfma.hip, round 6;
+        # int8 MFMA in rounds 2-5): priced against the dense fp4 peak, 2 ops per binary MAC; the popcount kernel (other geometries)
+        # against the same peak
         t = 2.0 * ops / sec / 1e12
-        r = {'bound': 'mfma', 'achieved': t, 'peak': MFMA_I8_PEAK_T, 'unit': 'TOP/s', 'frac': t / MFMA_I8_PEAK_T,
-             'note': 'int8 MFMA, dense peak = 2 x bf16 (the guide\'s micro-benchmark reaches 3944); achieved = 2 x binary MACs; '
-                     'SURVEY 8(d) popcount figure: %.0f T binary-MAC/s = %.2f of 1258' % (t / 2, t / 2 / POPCOUNT_PEAK_T),
+        r = {'bound': 'mfma', 'achieved': t, 'peak': MFMA_FP4_PEAK_T, 'unit': 'TOP/s', 'frac': t / MFMA_FP4_PEAK_T,
+             'frac_of_int8_peak': t / MFMA_I8_PEAK_T,
+             'note': 'fp4 (MX, unit scales) MFMA, dense peak 10 POP/s = 2 x int8 (the guide\'s micro-benchmark reaches 9099); achieved = 2 x '
+                     'binary MACs; rounds 2-5 priced the int8 kernel against 5 POP/s (frac_of_int8_peak); SURVEY 8(d) popcount figure: '
+                     '%.0f T binary-MAC/s = %.2f of 1258' % (t / 2, t / 2 / POPCOUNT_PEAK_T),
              'secondary': hbm}
     elif name == 'lsq_signw_conv2d':
         t = ops / sec / 1e12
@@ -581,7 +585,7 @@ def main():
             'steps_timed': steps_timed, 'repetitions': reps, 'timed_seconds': elapsed,
             'ms_per_step': 1e3 * elapsed / steps_timed, 'ms_per_step_best_repetition': min(rep_ms),
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'i8 mfma on sign bits (exact integers) + f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16 mfma (hi+lo split) + f32' if args.act == 'fp' else 'fp4 (e2m1, unit block scales) mfma on sign bits: exact integers in the f32 accumulator + f32', 'data': 'synthetic',
             'config': {'workload': f'ResNet-18 ImageNet ls-1 weight / {args.act} activation, '
                                    f'synthetic 3x{args.image_size}x{args.image_size}, batch {args.batch} per GPU, random-init weights',
                        'global_batch': world * args.batch,

@@ -641,22 +641,33 @@ int launch_y3(const ConvArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-template <int KX, int GG>
+template <int KX, int GG, bool FP4 = true>
 int launch(const ConvArgs& a, hipStream_t st) {
-  constexpr int NWAVES = GG >= 4 ? 8 : 4;
-  // workgroups per CU: one of 8 waves for 256 / 512 channels (see NWAVES above); below that three workgroups of 4 waves
-  // (168 VGPRs each) hide more of the epilogue's memory latency than two (re-measured in round 4: 128 channels on two
-  // workgroups or on one of 8 waves: no better)
-  constexpr int WPC = GG >= 4 ? 1 : 3;
+  // launch shape per channel count: waves per workgroup, workgroups per CU, and WPC = the waves per SIMD the register
+  // allocation must allow (__launch_bounds__'s second argument).  64 / 128 channels: three workgroups of 4 waves (168 VGPRs)
+  // hide more of the epilogue's memory latency than two (re-measured in round 4).  256 / 512 channels: ONE workgroup per CU (the
+  // set-up -- weight expansion, tables -- is paid once per CU), since the fp4 kernel of TWELVE waves: its fragments are half
+  // the int8 kernel's (42 / 79 KB of LDS) and it needs 167 / 159 registers, so three waves per SIMD fit where the int8 kernel
+  // ran two (scripts/xnor_shapes.py, profiles/r06_xnor_shapes.txt: 49.0 -> 47.5 / 29.8 -> 28.0 / 40.9 -> 40.1 us per layer;
+  // three workgroups of 4 or two of 6: slower).
+#ifndef LSQ_G4_SHAPE
+#define LSQ_G4_SHAPE 12, 1, 3
+#endif
+#ifndef LSQ_G8_SHAPE
+#define LSQ_G8_SHAPE 12, 1, 3
+#endif
+  constexpr int kShape[4][3] = {{4, 3, 3}, {LSQ_G4_SHAPE}, {LSQ_G8_SHAPE}, {8, 1, 1}};
+  constexpr int kS = GG < 4 ? 0 : (!FP4 ? 3 : (GG >= 8 ? 2 : 1));        // (the int8 comparator: 181 registers, its shape of rounds 4-5)
+  constexpr int NWAVES = kShape[kS][0], kWgsPerCu = kShape[kS][1], WPC = kShape[kS][2];
   const long long total = (long long)a.N * a.Ho * a.Wo;
   const long long ntiles = (total + 31) >> 5;
   const int n_ot = a.O / 32;
   // every resident wave strides over the pixel tiles of its workgroup's out-channel tile
-  const int wgs = 256 * WPC;
+  const int wgs = 256 * kWgsPerCu;
   long long gx = (wgs + n_ot - 1) / n_ot;
   gx = gx < 1 ? 1 : gx;
   if (gx * NWAVES > ntiles) gx = (ntiles + NWAVES - 1) / NWAVES;
-  if (a.y_s3 || a.res_s3) {
+  if constexpr (FP4) if (a.y_s3 || a.res_s3) {
     // three-stream tensors: the two-plane kernels of 64 / 128 channels (the 56 x 56 and 28 x 28 layers of the network, whose
     // rows are the long ones); a three-stream OUTPUT means tiles at pixel stride 3, whose bookkeeping wants the tile stride
     // of a wave to be a multiple of 3
@@ -668,18 +679,28 @@ int launch(const ConvArgs& a, hipStream_t st) {
       return kXnorMfmaNoLayout;
     }
   }
-  if (KX == 1 && (a.xunits || a.nq_planes32))
-    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
-  else
-    if (a.int8_mfma)          // (test hook lsq_debug_xnor_impl(2): round 2-5's int8 kernel, the fp4 kernel's comparator -- same bits)
-      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  if constexpr (!FP4) {
+    hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false, false>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  } else {
+    if (KX == 1 && (a.xunits || a.nq_planes32))
+      hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, KX == 1, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
     else
       hipLaunchKernelGGL((xnor_mfma_kernel<KX, GG, 9, NWAVES, WPC, false, false, false, true>), dim3((unsigned)gx, (unsigned)n_ot), dim3(64 * NWAVES), 0, st, a);
+  }
   return (int)hipGetLastError();
 }
 
 template <int KX>
 int launch_gg(const ConvArgs& a, hipStream_t st) {
+  // (test hook lsq_debug_xnor_impl(2): rounds 2-5's int8 kernel, the fp4 kernel's comparator -- same bits; plain calls only)
+  if (a.int8_mfma && !a.y_s3 && !a.res_s3 && !a.xunits && !a.nq_planes32) {
+    switch (a.cg) {
+      case 64: return launch<KX, 1, false>(a, st);
+      case 128: return launch<KX, 2, false>(a, st);
+      case 256: return launch<KX, 4, false>(a, st);
+      case 512: return launch<KX, 8, false>(a, st);
+    }
+  }
   switch (a.cg) {
     case 64: return launch<KX, 1>(a, st);
     case 128: return launch<KX, 2>(a, st);
