@@ -51,4 +51,10 @@ LSQ_RECORD_PARITY=1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_rou
 cp $o/free_running_observed.json $o/${tag}_free_running_parity.json
 scripts/pmc_icache.sh $o/${tag}_pmc_icache.txt > $o/pmc_icache.log 2>&1
 python scripts/sched_variants.py 40 > $o/${tag}_sched_variants.txt 2>&1
+# round 6: the convolution's three implementations side by side (fp4 / int8 matrix cores, popcount), the known-answer test of the
+# fp4 instruction, and the three-stream row layout (conv operand layouts in isolation, the network with it on and off)
+for impl in 0 2 1; do python scripts/xnor_shapes.py $impl; done > $o/${tag}_xnor_shapes.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/fp4_mfma_check.hip -o /tmp/fp4_check 2> $o/fp4_check.build.log && /tmp/fp4_check > $o/${tag}_ubench_fp4_mfma_check.txt 2>&1
+python scripts/xnor_s3.py > $o/${tag}_split3_conv_variants.txt 2>&1
+python scripts/split3_ab.py > $o/${tag}_split3_ab.txt 2>&1
 head -3 $o/${tag}_rocprofv3_per_step_summary.csv; cut -c1-300 $o/${tag}_bench_n1_ls2.json; cut -c1-160 $o/${tag}_bench_n1_fpact.json

@@ -21,7 +21,7 @@ def case(n, c, h, o, stride):
     bias = torch.randn(o, generator=g).to(DEV)
     return geom, planes, scales, wbits, wsum, wsc, bias
 
-for shape in [(256, 64, 56, 64, 1), (256, 128, 28, 128, 1)]:
+for shape in [(256, 64, 56, 64, 1), (256, 64, 56, 128, 2), (256, 128, 28, 128, 1)]:
     geom, planes, scales, wbits, wsum, wsc, bias = case(*shape)
     n, c, h, o, s = shape
     ho, wo = hip.out_hw(geom)

@@ -1,11 +1,14 @@
 """Developer tool: lsq_xnor_conv2d on the seven ResNet-18 layer shapes at batch 256 with the network's epilogue (ReLU + one
-residual), median of 30 launches with the buffers rotated; LSQ_HIP_LIB selects the build."""
+residual), median of 30 launches with the buffers rotated; LSQ_HIP_LIB selects the build, argv[1] the implementation
+(lsq_debug_xnor_impl: 0 fp4 matrix-core kernel, 1 popcount kernel, 2 int8 matrix-core kernel)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'ml-quant_amd')]
 import torch
 from quant import _hip as hip
 DEV = 'cuda:0'
+IMPL = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+hip.xnor_impl(IMPL)
 SHAPES = [(64, 56, 64, 1, 4), (64, 56, 128, 2, 1), (128, 28, 128, 1, 3), (128, 28, 256, 2, 1), (256, 14, 256, 1, 3), (256, 14, 512, 2, 1), (512, 7, 512, 1, 3)]
 tot = 0.0
 out = []
@@ -39,4 +42,4 @@ for c, h, o, s, cnt in SHAPES:
     us = sorted(1e3 * a.elapsed_time(b) for a, b in ts)[15]
     tot += us * cnt
     out.append(f'C{c}_H{h}_s{s} {us:6.1f}')
-print('  '.join(out), f' | 16 layers {tot / 1e3:.3f} ms')
+print(['fp4 ', 'popc', 'int8'][IMPL], '  '.join(out), f' | 16 layers {tot / 1e3:.3f} ms')
