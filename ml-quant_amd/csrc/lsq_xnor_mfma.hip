@@ -644,20 +644,24 @@ int launch_y3(const ConvArgs& a, hipStream_t st) {
 template <int KX, int GG, bool FP4 = true>
 int launch(const ConvArgs& a, hipStream_t st) {
   // launch shape per channel count: waves per workgroup, workgroups per CU, and WPC = the waves per SIMD the register
-  // allocation must allow (__launch_bounds__'s second argument).  64 / 128 channels: three workgroups of 4 waves (168 VGPRs)
-  // hide more of the epilogue's memory latency than two (re-measured in round 4).  256 / 512 channels: ONE workgroup per CU (the
-  // set-up -- weight expansion, tables -- is paid once per CU), since the fp4 kernel of TWELVE waves: its fragments are half
-  // the int8 kernel's (42 / 79 KB of LDS) and it needs 167 / 159 registers, so three waves per SIMD fit where the int8 kernel
-  // ran two (scripts/xnor_shapes.py, profiles/r06_xnor_shapes.txt: 49.0 -> 47.5 / 29.8 -> 28.0 / 40.9 -> 40.1 us per layer;
-  // three workgroups of 4 or two of 6: slower).
+  // allocation must allow (__launch_bounds__'s second argument).  The fp4 kernel runs as ONE workgroup of TWELVE waves per CU
+  // for every channel count: the set-up -- weight expansion, tables -- is paid once per CU, and 145 / 165 / 167 / 159 registers
+  // allow three waves per SIMD (the int8 kernel's 181 allowed two at 256 / 512 channels).  Measured (scripts/xnor_shapes.py,
+  // profiles/r06_xnor_ablation.txt): 64 / 128 channels against rounds 2-5's three workgroups of 4 waves 91.3 -> 89.9 / 55.1 ->
+  // 51.1 / 60.8 -> 57.2 / 43.5 -> 39.7 us per layer (two workgroups of 6: 119 us -- the second one does not always fit its
+  // waves onto the SIMDs the first left free); 256 / 512 channels against one workgroup of 8: 49.0 -> 47.5 / 29.8 -> 28.0 /
+  // 40.9 -> 40.1.
 #ifndef LSQ_G4_SHAPE
 #define LSQ_G4_SHAPE 12, 1, 3
 #endif
 #ifndef LSQ_G8_SHAPE
 #define LSQ_G8_SHAPE 12, 1, 3
 #endif
-  constexpr int kShape[4][3] = {{4, 3, 3}, {LSQ_G4_SHAPE}, {LSQ_G8_SHAPE}, {8, 1, 1}};
-  constexpr int kS = GG < 4 ? 0 : (!FP4 ? 3 : (GG >= 8 ? 2 : 1));        // (the int8 comparator: 181 registers, its shape of rounds 4-5)
+#ifndef LSQ_G1_SHAPE
+#define LSQ_G1_SHAPE 12, 1, 3
+#endif
+  constexpr int kShape[5][3] = {{LSQ_G1_SHAPE}, {LSQ_G4_SHAPE}, {LSQ_G8_SHAPE}, {8, 1, 1}, {4, 3, 3}};
+  constexpr int kS = !FP4 ? (GG < 4 ? 4 : 3) : (GG >= 8 ? 2 : (GG >= 4 ? 1 : 0));   // (the int8 comparator: its shapes of rounds 4-5)
   constexpr int NWAVES = kShape[kS][0], kWgsPerCu = kShape[kS][1], WPC = kShape[kS][2];
   const long long total = (long long)a.N * a.Ho * a.Wo;
   const long long ntiles = (total + 31) >> 5;
