@@ -225,7 +225,9 @@ int lsq_pack_weight(const float* w, const lsq_conv_geom* g, int k, const float* 
                     uint64_t* wbits, int32_t* wsum, void* stream);
 
 /*
- * Binary x binary convolution by XNOR + popcount:
+ * Binary x binary convolution -- exact integer inner products of sign planes: 3x3 kernels over 64 / 128 / 256 / 512 channels on the
+ * matrix cores (sign bits as fp4 operands of v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales: every product +-2 or 0, the fp32
+ * accumulator holds the integer), every other geometry by XNOR + popcount; both give the same bits:
  *   y[n][o] = bias[o] + sum_p sum_q xs[p][n] * ws[q][o] * (plane_p (*) wplane_q)[n][o]
  * which equals F.conv2d(x_q, w_q, bias, ...) of binary_conv.py:165-173 for
  * x_q = sum_p xs_p b_p, w_q = sum_q ws_q s_q (exact integer inner products).
