@@ -299,3 +299,43 @@ def test_non_finite_rows_stay_contained_in_the_windowed_solve():
                     a = p_bad.view(2, 4, words)[plane, row]
                     assert torch.equal(a, p_ok.view(2, 4, words)[plane, row]), (c, h, ternary, row, plane)
             assert s_bad[0, 2] == s_cl[0, 2] and torch.equal(p_bad.view(2, 4, words)[:, 2], p_cl.view(2, 4, words)[:, 2])
+
+
+@pytest.mark.parametrize('cin', [64, 128, 256, 512])
+def test_fp4_convolution_at_the_extremes_of_its_integer_range(cin):
+    """The fp4 matrix-core kernel's accumulator holds (b * s) as an fp32 integer: at most 9 * C = 4608 in magnitude.  All-(+1) and
+    all-(-1) activations against all-(+1) weights reach the extremes on interior pixels (and every border pattern's correction on
+    the rim): the output is the closed form, and equal to the popcount and int8 kernels bit for bit; fp4 codes of every slot
+    (0.5 / 1 / 2 / 0.5 against 4 / 2 / 1 / 4) are exercised by single-channel impulses."""
+    hip = _hip()
+    n, h, o = 3, 9, 64
+    geom = hip.make_geom(n, cin, h, h, o, 3, 3, (1, 1), (1, 1), (1, 1), 1)
+    wt = torch.ones(o, cin, 3, 3, device=DEV)
+    wt[1::2] = -1.0                                           # odd out-channels: all -1
+    wsc = torch.full((1, o), 0.5, device=DEV)
+    wbits, wsum = hip.pack_weight(wt, geom, wsc)
+    bias = torch.arange(o, dtype=torch.float32, device=DEV)
+    planes = torch.zeros((2 * hip.act_plane_words(geom),), dtype=torch.int64, device=DEV)
+    scales = torch.empty((2, n), dtype=torch.float32, device=DEV)
+    cases = {'plus': torch.full((n, cin, h, h), 2.0), 'minus': torch.full((n, cin, h, h), -2.0)}
+    imp = torch.full((n, cin, h, h), -2.0)
+    for c in range(0, cin, 5):
+        imp[:, c, (c // 5) % h, (c // 3) % h] = 2.0           # single +1 bits in every channel slot
+    cases['impulses'] = imp
+    for tag, x in cases.items():
+        # planes with given scales (v1 = 1, v2 = 0.25): plane 1 = sign(x), plane 2 = sign(x - v1 b1) = sign(x) for |x| = 2
+        forced = torch.tensor([[1.0] * n, [0.25] * n], device=DEV)
+        hip.act_quant(x.to(DEV), geom, hip.SCHEME_LS2, 2, 3, 3.0, planes, scales, forced)
+        outs = []
+        for impl in (1, 0, 2):
+            with hip.debug_switches(xnor_popcount=impl):
+                y = torch.empty((n, o, h, h), device=DEV)
+                hip.xnor_conv2d(planes, 2, scales, wbits, wsum, wsc, bias, geom, y)
+                outs.append(y.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (cin, tag)
+        if tag != 'impulses':
+            taps = torch.nn.functional.conv2d(torch.ones(1, 1, h, h), torch.ones(1, 1, 3, 3), padding=1).view(h, h).to(DEV)   # taps inside the image
+            s1 = 1.0 if tag == 'plus' else -1.0
+            sign_o = torch.where(torch.arange(o, device=DEV) % 2 == 0, 1.0, -1.0)
+            want = bias.view(1, o, 1, 1) + 0.5 * sign_o.view(1, o, 1, 1) * (1.0 * s1 + 0.25 * s1) * cin * taps.view(1, 1, h, h)
+            assert torch.equal(outs[1], want.expand(n, o, h, h).contiguous()), (cin, tag, float((outs[1] - want).abs().max()))
